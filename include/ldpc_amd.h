@@ -1,0 +1,185 @@
+/*
+ * ldpc_amd.h -- C ABI of the MI355X (gfx950) flooding belief-propagation LDPC decoder.
+ *
+ * The reference has no FFI seam; its decoder boundary is the Java static method
+ *     LogDecoder.decode(int[][] encodedH, int[] r, double e, int maxL)
+ *         -> DecodeResult(int[] decodedCode, int iterationNum, int syndrome)
+ * (src/LDPC/LogDecoder.java:15-17; same shape in LogDecoderBefore.java:15-17 and
+ * MinSumDecoder.java:9-11).  This header is what a Panama-FFM / JNI / ctypes binding of
+ * that boundary binds: the parity-check matrix goes in once (create), frames go in as
+ * batches, hard decisions + iteration count + syndrome weight come out per frame.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative LDPC_AMD_E* code on failure;
+ *     ldpc_amd_last_error() gives the text.  Nothing throws or aborts across the ABI.
+ *   - a context is bound to one GPU, owns its device buffers, and is not re-entrant;
+ *     distinct contexts (one per GPU / per thread) are independent.
+ *   - "host" entry points take host pointers and stage through the device;
+ *     "_dev" entry points take device pointers on the context's GPU plus a hipStream_t
+ *     (passed as void*, NULL = default stream) and never synchronise the host.
+ *   - per-frame outputs follow DecodeResult: hard[f][j] in {0,1}
+ *     (estimatedCode, LogDecoder.java:104), iters[f] = l+1 at the first zero syndrome or
+ *     max_iters (LogDecoder.java:118, :122), syndrome_weight[f] = number of unsatisfied
+ *     checks of the returned word (sumSyndro, LogDecoder.java:108-116).
+ */
+#ifndef LDPC_AMD_H
+#define LDPC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDPC_AMD_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define LDPC_AMD_OK 0
+#define LDPC_AMD_EINVAL (-1)  /* bad argument */
+#define LDPC_AMD_ENOMEM (-2)  /* host or device allocation failed */
+#define LDPC_AMD_EHIP (-3)    /* a HIP runtime call failed */
+#define LDPC_AMD_ENODEV (-4)  /* no usable gfx950 device */
+#define LDPC_AMD_ELIMIT (-5)  /* the code exceeds a compiled-in limit (node degree) */
+
+/* check-node rule */
+#define LDPC_AMD_CN_SUMPRODUCT 0 /* 2*atanh(prod tanh(beta/2)), LogDecoder.java:82-95 */
+#define LDPC_AMD_CN_MINSUM 1     /* 0.7 * prod sign * min|beta|, MinSumDecoder.java:76-94 */
+
+/* how decode_bsc_batch turns a hard received word into channel LLRs */
+#define LDPC_AMD_LLR_UNIFORM 0       /* +-ln((1-e)/e) everywhere, LogDecoderBefore.java:45-50 */
+#define LDPC_AMD_LLR_PARITY_LN1E20 1 /* j >= n-m get +-ln(1e20), LogDecoder.java:45-54 */
+#define LDPC_AMD_LLR_PARITY_1EM7 2   /* j >= n-m get +-ln((1-1e-7)/1e-7), MinSumDecoder.java:41 */
+
+/* channels of ldpc_amd_simulate */
+#define LDPC_AMD_CH_BSC_INFO 0 /* flips on j < n-m only, Channel.java:5-17; LLRs as LogDecoder */
+#define LDPC_AMD_CH_BSC_ALL 1  /* flips everywhere, Channel.java:28-39; LLRs as LogDecoderBefore */
+#define LDPC_AMD_CH_AWGN 2     /* BPSK + AWGN at Eb/N0 dB (not in the reference) */
+
+/* layout of the counter vector of ldpc_amd_simulate / ldpc_amd_count_errors_dev:
+ * the statistics of LDPC_GallagerIntStreamSimu.java:136-183 for the all-zero codeword */
+#define LDPC_AMD_CNT_FRAMES 0
+#define LDPC_AMD_CNT_FRAME_ERRORS 1      /* !Arrays.equals(c, decodedC), :136 */
+#define LDPC_AMD_CNT_INFO_BIT_ERRORS 2   /* residualsErrorInfoBits, :156-161 */
+#define LDPC_AMD_CNT_CHECK_BIT_ERRORS 3  /* errorCheckBitsCounter, :167-172 */
+#define LDPC_AMD_CNT_INFO_FRAME_ERRORS 4 /* errorInfoFrameCounter, :176 */
+#define LDPC_AMD_CNT_CHECK_FRAME_ERRORS 5 /* errorCheckFrameCounter, :173 */
+#define LDPC_AMD_CNT_UNDETECTED 6        /* syndrome == 0 && !correct, :182 */
+#define LDPC_AMD_CNT_MISCORRECTED 7      /* errorCorrectionBits, :162-164 */
+#define LDPC_AMD_CNT_ITERS_CORRECT 8     /* trueIterations[0], :148 */
+#define LDPC_AMD_CNT_ITERS_WRONG 9       /* falseIterations[0], :151 */
+#define LDPC_AMD_CNT_CHANNEL_ERRORS 10   /* sum over frames of info-bit channel errors, Channel.java:18-27 */
+#define LDPC_AMD_CNT_CHANNEL_ERRORS_SQ 11 /* sum of their squares (for the variance, :221-228) */
+#define LDPC_AMD_CNT_FIXED 16            /* histogram[it-1] starts here, :144; length max_iters */
+
+typedef struct ldpc_amd_ctx ldpc_amd_ctx;
+
+/* Library version (LDPC_AMD_VERSION of the build). */
+int ldpc_amd_version(void);
+
+/* Text of the last error on `ctx`, or of the last failed create when ctx is NULL. */
+const char* ldpc_amd_last_error(const ldpc_amd_ctx* ctx);
+
+/*
+ * Build a decoder for the m x n matrix whose ones are the COO pairs (row_idx[t], col_idx[t]).
+ * Replaces the per-frame adjacency build of LogDecoder.java:27-42: pairs may come in any
+ * order; they are sorted row-major so A(i) and B(j) are ascending as the reference's dense
+ * scan makes them; pairs outside the matrix are ignored and repeats collapse
+ * (CheckMatrixIO.java:37-45).  device_id < 0 selects the current HIP device.
+ */
+int ldpc_amd_create(int32_t m, int32_t n, int64_t nnz, const int32_t* row_idx, const int32_t* col_idx,
+                    int32_t device_id, ldpc_amd_ctx** out);
+int ldpc_amd_destroy(ldpc_amd_ctx* ctx);
+
+/* Shape queries: m, n, number of edges E, max check degree, max variable degree. */
+int ldpc_amd_info(const ldpc_amd_ctx* ctx, int32_t* m, int32_t* n, int64_t* edges, int32_t* max_dc,
+                  int32_t* max_dv);
+
+/* Host copies of the adjacency the kernels walk: row_ptr[m+1], edge_col[E] (A(i), ascending
+ * column, LogDecoder.java:35-42) and col_ptr[n+1], col_edge[E] (B(j) as CSR edge ids,
+ * ascending row).  Any pointer may be NULL. */
+int ldpc_amd_graph(const ldpc_amd_ctx* ctx, int32_t* row_ptr, int32_t* edge_col, int32_t* col_ptr,
+                   int32_t* col_edge);
+
+/* Check-node rule used by every later decode on this context (default sum-product). */
+int ldpc_amd_set_cn_rule(ldpc_amd_ctx* ctx, int32_t cn_rule);
+
+/* Cap on the bytes of device workspace a decode may hold (0 = default: 60 % of free HBM). */
+int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
+
+/*
+ * Decode `frames` frames from channel LLRs (lambda_j > 0 <=> bit 0, LogDecoder.java:50).
+ * Replaces the loop body LogDecoder.java:64-120 for a whole batch.
+ *   llr      [frames][n] float
+ *   early_term != 0: stop a frame at its first zero syndrome (the reference's behaviour);
+ *   early_term == 0: run exactly max_iters iterations (iters[f] = max_iters).
+ *   hard     [frames][n] uint8, iters [frames] int32, syndrome_weight [frames] int32
+ *   (iters / syndrome_weight may be NULL).
+ */
+int ldpc_amd_decode_batch(ldpc_amd_ctx* ctx, const float* llr, int64_t frames, int32_t max_iters,
+                          int32_t early_term, uint8_t* hard, int32_t* iters, int32_t* syndrome_weight);
+int ldpc_amd_decode_batch_dev(ldpc_amd_ctx* ctx, const float* d_llr, int64_t frames, int32_t max_iters,
+                              int32_t early_term, uint8_t* d_hard, int32_t* d_iters,
+                              int32_t* d_syndrome_weight, void* stream);
+
+/*
+ * The reference's own calling convention: hard received words r[frames][n] (uint8, 0/1)
+ * and the crossover probability e; channel LLRs are formed on the device exactly as
+ * LogDecoder.java:45-54 (llr_mode LDPC_AMD_LLR_PARITY_LN1E20), LogDecoderBefore.java:45-50
+ * (LDPC_AMD_LLR_UNIFORM) or MinSumDecoder.java:39-48 (LDPC_AMD_LLR_PARITY_1EM7) form them,
+ * in double on the host and rounded once to float.
+ */
+int ldpc_amd_decode_bsc_batch(ldpc_amd_ctx* ctx, const uint8_t* r, int64_t frames, double e,
+                              int32_t llr_mode, int32_t max_iters, int32_t early_term, uint8_t* hard,
+                              int32_t* iters, int32_t* syndrome_weight);
+int ldpc_amd_decode_bsc_batch_dev(ldpc_amd_ctx* ctx, const uint8_t* d_r, int64_t frames, double e,
+                                  int32_t llr_mode, int32_t max_iters, int32_t early_term,
+                                  uint8_t* d_hard, int32_t* d_iters, int32_t* d_syndrome_weight,
+                                  void* stream);
+
+/*
+ * On-device channel for the all-zero codeword, frames first_frame .. first_frame+frames-1.
+ * The generator is Philox4x32-10 keyed by `seed` with counter (frame, position/4, stream),
+ * so a frame's noise does not depend on how frames are split over calls or GPUs.
+ * Replaces Channel.GenerateR / GenerateRBefore (Channel.java:5-17, :28-39), whose
+ * java.util.Random is unseeded.
+ *   gen_bsc_dev : d_r   [frames][n] uint8, flip iff u32 < floor(e * 2^32)
+ *   gen_awgn_dev: d_llr [frames][n] float, 2*y/sigma^2 with y = 1 + sigma*N(0,1),
+ *                 sigma^2 = 1 / (2 * ((n-m)/n) * 10^(ebn0_db/10))
+ */
+int ldpc_amd_gen_bsc_dev(ldpc_amd_ctx* ctx, int32_t channel, double e, uint64_t seed, int64_t first_frame,
+                         int64_t frames, uint8_t* d_r, void* stream);
+int ldpc_amd_gen_awgn_llr_dev(ldpc_amd_ctx* ctx, double ebn0_db, uint64_t seed, int64_t first_frame,
+                              int64_t frames, float* d_llr, void* stream);
+
+/*
+ * Accumulate the statistics of LDPC_GallagerIntStreamSimu.java:136-183 (all-zero codeword)
+ * into d_counters[LDPC_AMD_CNT_FIXED + max_iters] (uint64, device).  d_rx_hard is the
+ * channel's hard decision per position ([frames][n] uint8); it may be NULL, then the
+ * miscorrected / channel-error counters are left untouched.
+ */
+int ldpc_amd_count_errors_dev(ldpc_amd_ctx* ctx, int64_t frames, const uint8_t* d_hard,
+                              const uint8_t* d_rx_hard, const int32_t* d_iters,
+                              const int32_t* d_syndrome_weight, int32_t max_iters, uint64_t* d_counters,
+                              void* stream);
+
+/*
+ * One Monte-Carlo leg on the GPU: generate, decode, count.  The whole frame loop of
+ * LDPC_GallagerIntStreamSimu.java:99-184 for one (matrix, channel parameter) point.
+ * `param` is e for the BSC channels and Eb/N0 in dB for AWGN.  counters is a HOST array
+ * of LDPC_AMD_CNT_FIXED + max_iters uint64 and is ACCUMULATED into (zero it first);
+ * summing the vectors of disjoint frame ranges gives the vector of their union.
+ */
+int ldpc_amd_simulate(ldpc_amd_ctx* ctx, int32_t channel, double param, uint64_t seed, int64_t first_frame,
+                      int64_t frames, int32_t max_iters, int32_t early_term, uint64_t* counters);
+
+/*
+ * Timing of the most recent decode on this context: number of launches of the
+ * message-passing kernel, their summed duration in milliseconds (HIP events on the
+ * stream the kernel ran on; synchronises that stream) and the frames they covered.
+ */
+int ldpc_amd_last_decode_timing(ldpc_amd_ctx* ctx, int32_t* launches, double* kernel_ms, int64_t* frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

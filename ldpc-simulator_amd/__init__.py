@@ -1,0 +1,11 @@
+"""MI355X-native flooding belief-propagation LDPC decoder (hot path of LDPC-Simulator).
+
+capi           ctypes binding of the C ABI (include/ldpc_amd.h -> libldpc_amd.so)
+log_decoder    LogDecoder / LogDecoderBefore / MinSumDecoder with the reference's signature
+codes          seeded parity-check matrix builders
+check_matrix_io  the reference's H text format
+sim            frame sharding over GPUs and the counter all-reduce
+"""
+from . import capi, check_matrix_io, codes, sim  # noqa: F401
+from .capi import Decoder, LdpcError  # noqa: F401
+from .log_decoder import DecodeResult, LogDecoder, LogDecoderBefore, MinSumDecoder  # noqa: F401

@@ -1,0 +1,194 @@
+"""ctypes binding of libldpc_amd.so (the C ABI declared in include/ldpc_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, loading or
+creating a decoder raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldpc_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ldpc_amd.h")
+
+OK, EINVAL, ENOMEM, EHIP, ENODEV, ELIMIT = 0, -1, -2, -3, -4, -5
+CN_SUMPRODUCT, CN_MINSUM = 0, 1
+LLR_UNIFORM, LLR_PARITY_LN1E20, LLR_PARITY_1EM7 = 0, 1, 2
+CH_BSC_INFO, CH_BSC_ALL, CH_AWGN = 0, 1, 2
+CNT_FRAMES, CNT_FRAME_ERRORS, CNT_INFO_BIT_ERRORS, CNT_CHECK_BIT_ERRORS = 0, 1, 2, 3
+CNT_INFO_FRAME_ERRORS, CNT_CHECK_FRAME_ERRORS, CNT_UNDETECTED, CNT_MISCORRECTED = 4, 5, 6, 7
+CNT_ITERS_CORRECT, CNT_ITERS_WRONG, CNT_CHANNEL_ERRORS, CNT_CHANNEL_ERRORS_SQ = 8, 9, 10, 11
+CNT_FIXED = 16
+
+_vp, _i32, _i64, _u64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+
+SIGNATURES = {
+    "ldpc_amd_version": (C.c_int, []),
+    "ldpc_amd_last_error": (C.c_char_p, [_vp]),
+    "ldpc_amd_create": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "ldpc_amd_destroy": (C.c_int, [_vp]),
+    "ldpc_amd_info": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "ldpc_amd_graph": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ldpc_amd_set_cn_rule": (C.c_int, [_vp, _i32]),
+    "ldpc_amd_set_workspace_limit": (C.c_int, [_vp, _u64]),
+    "ldpc_amd_decode_batch": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "ldpc_amd_decode_batch_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ldpc_amd_decode_bsc_batch": (C.c_int, [_vp, _vp, _i64, _f64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ldpc_amd_decode_bsc_batch_dev": (C.c_int, [_vp, _vp, _i64, _f64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ldpc_amd_gen_bsc_dev": (C.c_int, [_vp, _i32, _f64, _u64, _i64, _i64, _vp, _vp]),
+    "ldpc_amd_gen_awgn_llr_dev": (C.c_int, [_vp, _f64, _u64, _i64, _i64, _vp, _vp]),
+    "ldpc_amd_count_errors_dev": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "ldpc_amd_simulate": (C.c_int, [_vp, _i32, _f64, _u64, _i64, _i64, _i32, _i32, _vp]),
+    "ldpc_amd_last_decode_timing": (C.c_int, [_vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libldpc_amd.so and declare every entry point; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "%s not found: build it with `make -C ldpc-simulator_amd/csrc` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class LdpcError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("ldpc_amd error %d: %s" % (code, text))
+        self.code = code
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Decoder:
+    """One parity-check matrix on one GPU (an ldpc_amd_ctx)."""
+
+    def __init__(self, m, n, rows, cols, device=-1):
+        lib = load_library()
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        if rows.shape != cols.shape:
+            raise ValueError("rows and cols must have the same length")
+        h = C.c_void_p()
+        rc = lib.ldpc_amd_create(int(m), int(n), rows.size, _np_ptr(rows), _np_ptr(cols), int(device), C.byref(h))
+        if rc != OK:
+            raise LdpcError(rc, (lib.ldpc_amd_last_error(None) or b"").decode())
+        self._lib, self._h = lib, h
+        mm, nn, ee, dc, dv = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32(), C.c_int32()
+        lib.ldpc_amd_info(h, C.byref(mm), C.byref(nn), C.byref(ee), C.byref(dc), C.byref(dv))
+        self.m, self.n, self.E, self.max_dc, self.max_dv = mm.value, nn.value, ee.value, dc.value, dv.value
+
+    @classmethod
+    def from_dense(cls, H, device=-1):
+        H = np.asarray(H)
+        r, c = np.nonzero(H == 1)
+        return cls(H.shape[0], H.shape[1], r, c, device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ldpc_amd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise LdpcError(rc, (self._lib.ldpc_amd_last_error(self._h) or b"").decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def graph(self):
+        rp = np.zeros(self.m + 1, np.int32)
+        ec = np.zeros(max(self.E, 1), np.int32)
+        cp = np.zeros(self.n + 1, np.int32)
+        ce = np.zeros(max(self.E, 1), np.int32)
+        self._check(self._lib.ldpc_amd_graph(self._h, _np_ptr(rp), _np_ptr(ec), _np_ptr(cp), _np_ptr(ce)))
+        return rp, ec[: self.E], cp, ce[: self.E]
+
+    def set_cn_rule(self, rule):
+        self._check(self._lib.ldpc_amd_set_cn_rule(self._h, int(rule)))
+
+    def set_workspace_limit(self, nbytes):
+        self._check(self._lib.ldpc_amd_set_workspace_limit(self._h, int(nbytes)))
+
+    # ---- host-buffer entry points ------------------------------------------------------
+    def decode_batch(self, llr, max_iters, early_term=True):
+        llr = np.ascontiguousarray(llr, dtype=np.float32)
+        if llr.ndim != 2 or llr.shape[1] != self.n:
+            raise ValueError("llr must be [frames][n]")
+        f = llr.shape[0]
+        hard = np.zeros((f, self.n), np.uint8)
+        it = np.zeros(f, np.int32)
+        sw = np.zeros(f, np.int32)
+        self._check(self._lib.ldpc_amd_decode_batch(self._h, _np_ptr(llr), f, int(max_iters), int(bool(early_term)),
+                                                    _np_ptr(hard), _np_ptr(it), _np_ptr(sw)))
+        return hard, it, sw
+
+    def decode_bsc_batch(self, r, e, max_iters, llr_mode=LLR_PARITY_LN1E20, early_term=True):
+        r = np.ascontiguousarray(r, dtype=np.uint8)
+        if r.ndim != 2 or r.shape[1] != self.n:
+            raise ValueError("r must be [frames][n]")
+        f = r.shape[0]
+        hard = np.zeros((f, self.n), np.uint8)
+        it = np.zeros(f, np.int32)
+        sw = np.zeros(f, np.int32)
+        self._check(self._lib.ldpc_amd_decode_bsc_batch(self._h, _np_ptr(r), f, float(e), int(llr_mode), int(max_iters),
+                                                        int(bool(early_term)), _np_ptr(hard), _np_ptr(it), _np_ptr(sw)))
+        return hard, it, sw
+
+    def simulate(self, channel, param, seed, first_frame, frames, max_iters, early_term=True, counters=None):
+        if counters is None:
+            counters = np.zeros(CNT_FIXED + int(max_iters), np.uint64)
+        assert counters.dtype == np.uint64 and counters.size >= CNT_FIXED + int(max_iters)
+        self._check(self._lib.ldpc_amd_simulate(self._h, int(channel), float(param), int(seed), int(first_frame),
+                                                int(frames), int(max_iters), int(bool(early_term)), _np_ptr(counters)))
+        return counters
+
+    # ---- device-pointer entry points (addresses as ints, e.g. torch.Tensor.data_ptr()) ---
+    def decode_batch_dev(self, d_llr, frames, max_iters, early_term, d_hard, d_iters=0, d_synd=0, stream=0):
+        self._check(self._lib.ldpc_amd_decode_batch_dev(self._h, d_llr, int(frames), int(max_iters),
+                                                        int(bool(early_term)), d_hard, d_iters or None,
+                                                        d_synd or None, stream or None))
+
+    def decode_bsc_batch_dev(self, d_r, frames, e, llr_mode, max_iters, early_term, d_hard, d_iters=0, d_synd=0,
+                             stream=0):
+        self._check(self._lib.ldpc_amd_decode_bsc_batch_dev(self._h, d_r, int(frames), float(e), int(llr_mode),
+                                                            int(max_iters), int(bool(early_term)), d_hard,
+                                                            d_iters or None, d_synd or None, stream or None))
+
+    def gen_bsc_dev(self, channel, e, seed, first_frame, frames, d_r, stream=0):
+        self._check(self._lib.ldpc_amd_gen_bsc_dev(self._h, int(channel), float(e), int(seed), int(first_frame),
+                                                   int(frames), d_r, stream or None))
+
+    def gen_awgn_llr_dev(self, ebn0_db, seed, first_frame, frames, d_llr, stream=0):
+        self._check(self._lib.ldpc_amd_gen_awgn_llr_dev(self._h, float(ebn0_db), int(seed), int(first_frame),
+                                                        int(frames), d_llr, stream or None))
+
+    def count_errors_dev(self, frames, d_hard, d_rx_hard, d_iters, d_synd, max_iters, d_counters, stream=0):
+        self._check(self._lib.ldpc_amd_count_errors_dev(self._h, int(frames), d_hard, d_rx_hard or None, d_iters,
+                                                        d_synd, int(max_iters), d_counters, stream or None))
+
+    def last_decode_timing(self):
+        n, ms, fr = C.c_int32(), C.c_double(), C.c_int64()
+        self._check(self._lib.ldpc_amd_last_decode_timing(self._h, C.byref(n), C.byref(ms), C.byref(fr)))
+        return n.value, ms.value, fr.value

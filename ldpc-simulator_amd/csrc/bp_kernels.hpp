@@ -1,0 +1,503 @@
+// Flooding belief-propagation kernels for gfx950 (wave64).
+//
+// Mapping: one wavefront owns one tile of T = 64*FPL frames for the whole decode; lane l
+// carries frames l*FPL .. l*FPL+FPL-1 of the tile.  Every message array is frame-major,
+// msg[edge][T], so a wave's access to one edge is one contiguous T*4-byte row whatever the
+// structure of H, and the CSR/CSC indices are wave-uniform (scalar loads).  Frames never
+// interact, so a wave needs no barrier and no other wave's data: the loop
+// LogDecoder.java:64-120 runs start to end inside one launch.
+//
+// One iteration (reference order: VN :67-79, CN :82-95, decide :98-105, syndrome :108-116)
+// is restated as  CN sweep -> VN sweep that also forms gamma/decisions -> syndrome.  The
+// VN sweep of iteration l produces the beta of iteration l+1 from the same alpha reads that
+// give gamma of iteration l; the first CN sweep reads beta = lambda (+ 0.0, the sum of the
+// zero-initialised alpha of :57) straight from the channel LLRs.
+//
+// A single message array is updated in place: the CN sweep turns row beta[e] into
+// alpha[e], the VN sweep turns it back.  Leave-one-out sums and products are prefix x
+// suffix combinations; nothing is ever subtracted or divided out, so +-Inf and NaN behave
+// as in the reference (Inf - Inf never appears where the reference has a finite value).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ldpc {
+
+constexpr int kWave = 64;
+constexpr int kCnSumProduct = 0;
+constexpr int kCnMinSum = 1;
+#ifndef LDPC_REG_DEG_FPL1
+#define LDPC_REG_DEG_FPL1 16
+#endif
+constexpr int kRegDegFpl1 = LDPC_REG_DEG_FPL1;  // node degrees handled in registers, 1 frame per lane
+constexpr int kRegDegFpl4 = 8;   // ... and with 2 or 4 frames per lane
+
+struct BpParams {
+    int m, n, nw;            // checks, variables, 32-bit decision words per frame
+    const int* row_ptr;      // [m+1] CSR: edges of check i, ascending column
+    const int* edge_col;     // [E]
+    const int* col_ptr;      // [n+1] CSC
+    const int* col_edge;     // [E]   CSR edge id of each entry of B(j), ascending row
+    float* ws_msg;           // [tiles][E][T]
+    const float* ws_lam;     // [tiles][n][T]
+    uint32_t* ws_bits;       // [tiles][nw][T] packed decisions, bit (j & 31) of word j >> 5
+    long long msg_stride, lam_stride, bits_stride;  // per-tile strides in elements
+    int tiles;               // tiles in this launch
+    long long frame_base;    // batch index of frame 0 of tile 0
+    long long frames_total;  // frames in the batch
+    int max_iters;
+    int32_t* out_iters;      // [frames_total] or null
+    int32_t* out_synd;       // [frames_total] or null
+    int lds_maxd;            // rows of LDS staging per wave and array (0 = no LDS path)
+};
+
+// ---- vector access helpers: FPL consecutive floats / words per lane -------------------
+template <int FPL>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[FPL]) {
+    if constexpr (FPL == 1) {
+        v[0] = p[0];
+    } else if constexpr (FPL == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x; v[1] = t.y;
+    } else {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+}
+template <int FPL>
+__device__ __forceinline__ void stv(float* p, const float (&v)[FPL]) {
+    if constexpr (FPL == 1) {
+        p[0] = v[0];
+    } else if constexpr (FPL == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+    } else {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+template <int FPL>
+__device__ __forceinline__ void ldw(const uint32_t* p, uint32_t (&v)[FPL]) {
+    if constexpr (FPL == 1) {
+        v[0] = p[0];
+    } else if constexpr (FPL == 2) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        v[0] = t.x; v[1] = t.y;
+    } else {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+}
+template <int FPL>
+__device__ __forceinline__ void stw(uint32_t* p, const uint32_t (&v)[FPL]) {
+    if constexpr (FPL == 1) {
+        p[0] = v[0];
+    } else if constexpr (FPL == 2) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(v[0], v[1]);
+    } else {
+        *reinterpret_cast<uint4*>(p) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---- check-node arithmetic -----------------------------------------------------------
+// tanh(b/2), the factor of LogDecoder.java:90.  1 - 2/(e^b + 1) on the hardware exp2/rcp;
+// +-Inf give +-1 exactly and NaN stays NaN, as Math.tanh does.  Below |b| = 0.25 the
+// quotient cancels, so the odd Taylor polynomial is used there (error < 2e-9 relative).
+__device__ __forceinline__ float tanh_half(float b) {
+    const float e = __builtin_amdgcn_exp2f(b * 1.4426950408889634f);
+    const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+    const float big = fmaf(-2.0f, r, 1.0f);
+    const float h = 0.5f * b;
+    const float h2 = h * h;
+    const float poly = h * fmaf(h2, fmaf(h2, fmaf(h2, -17.0f / 315.0f, 2.0f / 15.0f), -1.0f / 3.0f), 1.0f);
+    return (fabsf(b) < 0.25f) ? poly : big;
+}
+
+// 2*atanh(p) = ln((1+p)/(1-p)), LogDecoder.java:9-11 and :93.  p = +-1 gives +-Inf
+// (2/0 and ln 0), NaN stays NaN.  Below |p| = 0.15 the logarithm cancels, so the series
+// 2(p + p^3/3 + ... + p^9/9) is used there.
+__device__ __forceinline__ float atanh2(float p) {
+    const float q = (1.0f + p) * __builtin_amdgcn_rcpf(1.0f - p);
+    const float big = __builtin_amdgcn_logf(q) * 0.6931471805599453f;
+    const float p2 = p * p;
+    const float ser =
+        2.0f * p * fmaf(p2, fmaf(p2, fmaf(p2, fmaf(p2, 1.0f / 9.0f, 1.0f / 7.0f), 1.0f / 5.0f), 1.0f / 3.0f), 1.0f);
+    return (fabsf(p) < 0.15f) ? ser : big;
+}
+
+// Math.signum: +-0 and NaN map to themselves (MinSumDecoder.java:84)
+__device__ __forceinline__ float signum(float x) { return (x > 0.0f) ? 1.0f : (x < 0.0f) ? -1.0f : x; }
+
+// beta[0..D) -> alpha[0..D) in place, D a compile-time degree.
+template <int FPL, int D, int RULE>
+__device__ __forceinline__ void cn_compute(float (&b)[D][FPL]) {
+    if constexpr (RULE == kCnSumProduct) {
+        float pre[D][FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) pre[0][f] = 1.0f;  // "double product = 1.0", LogDecoder.java:86
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) {
+                const float t = tanh_half(b[k][f]);
+                b[k][f] = t;
+                if (k + 1 < D) pre[k + 1][f] = pre[k][f] * t;
+            }
+        float suf[FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) suf[f] = 1.0f;
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k)
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) {
+                const float p = pre[k][f] * suf[f];
+                suf[f] *= b[k][f];
+                b[k][f] = atanh2(p);
+            }
+    } else {
+        // MinSumDecoder.java:79-93: alpha = prod signum(beta) * min|beta| * 0.7 over k != j;
+        // "minbata > |beta|" never selects a NaN, and Double.MAX_VALUE becomes FLT_MAX.
+        float ps[D][FPL], pm[D][FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) { ps[0][f] = 1.0f; pm[0][f] = 3.402823466e+38f; }
+#pragma unroll
+        for (int k = 0; k + 1 < D; ++k)
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) {
+                const float a = fabsf(b[k][f]);
+                ps[k + 1][f] = ps[k][f] * signum(b[k][f]);
+                pm[k + 1][f] = (pm[k][f] > a) ? a : pm[k][f];
+            }
+        float ss[FPL], sm[FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) { ss[f] = 1.0f; sm[f] = 3.402823466e+38f; }
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k)
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) {
+                const float a = fabsf(b[k][f]);
+                const float sg = signum(b[k][f]);
+                const float mn = (pm[k][f] > sm[f]) ? sm[f] : pm[k][f];
+                b[k][f] = ps[k][f] * ss[f] * mn * 0.7f;
+                ss[f] *= sg;
+                sm[f] = (sm[f] > a) ? a : sm[f];
+            }
+    }
+}
+
+// One check of compile-time degree D.  `row` points at this lane's slot of the check's first
+// edge row; FIRST reads beta = lambda + 0.0 through the column indices instead.
+template <int FPL, int D, int RULE, bool FIRST>
+__device__ __forceinline__ void cn_row(float* row, const float* lam, const int* cols, int T) {
+    float b[D][FPL];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        if constexpr (FIRST) {
+            ldv<FPL>(lam + (long long)cols[k] * T, b[k]);
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) b[k][f] += 0.0f;
+        } else {
+            ldv<FPL>(row + (long long)k * T, b[k]);
+        }
+    }
+    cn_compute<FPL, D, RULE>(b);
+#pragma unroll
+    for (int k = 0; k < D; ++k) stv<FPL>(row + (long long)k * T, b[k]);
+}
+
+// Any degree up to the LDS capacity, one frame per lane: tanh values and exclusive prefix
+// products of the row are staged in LDS as [k][lane] (conflict-free), then combined with
+// the running suffix product on the way back.
+template <int RULE, bool FIRST>
+__device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const int* cols, int T, int d,
+                                           float* lds, int cap, int lane) {
+    float* st = lds + lane;                 // [k][64]: tanh (or beta for min-sum)
+    float* sp = lds + (long long)cap * 64 + lane;  // [k][64]: exclusive prefix product / prefix min
+    if constexpr (RULE == kCnSumProduct) {
+        float pre = 1.0f;
+        for (int k = 0; k < d; ++k) {
+            float b = FIRST ? (lam[(long long)cols[k] * T] + 0.0f) : row[(long long)k * T];
+            const float t = tanh_half(b);
+            st[k * 64] = t;
+            sp[k * 64] = pre;
+            pre *= t;
+        }
+        float suf = 1.0f;
+        for (int k = d - 1; k >= 0; --k) {
+            const float p = sp[k * 64] * suf;
+            suf *= st[k * 64];
+            row[(long long)k * T] = atanh2(p);
+        }
+    } else {
+        // beta and the exclusive prefix minimum are staged; the exclusive prefix sign product
+        // of row k is rebuilt from the staged beta on the way back (this path is rare).
+        float pm = 3.402823466e+38f;
+        for (int k = 0; k < d; ++k) {
+            float b = FIRST ? (lam[(long long)cols[k] * T] + 0.0f) : row[(long long)k * T];
+            st[k * 64] = b;
+            sp[k * 64] = pm;
+            const float a = fabsf(b);
+            pm = (pm > a) ? a : pm;
+        }
+        float ss = 1.0f, sm = 3.402823466e+38f;
+        for (int k = d - 1; k >= 0; --k) {
+            const float b = st[k * 64];
+            float psign = 1.0f;
+            for (int q = 0; q < k; ++q) psign *= signum(st[q * 64]);
+            const float pmin = sp[k * 64];
+            const float mn = (pmin > sm) ? sm : pmin;
+            row[(long long)k * T] = psign * ss * mn * 0.7f;
+            ss *= signum(b);
+            const float a = fabsf(b);
+            sm = (sm > a) ? a : sm;
+        }
+    }
+}
+
+// ---- variable-node arithmetic --------------------------------------------------------
+// alpha[0..D) -> beta[0..D) in place; g = lambda + sum alpha, accumulated in ascending
+// order from lambda exactly as gamma is (LogDecoder.java:100-103).
+template <int FPL, int D>
+__device__ __forceinline__ void vn_compute(float (&a)[D][FPL], const float (&lam)[FPL], float (&g)[FPL]) {
+    float pre[D + 1][FPL];
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) pre[0][f] = lam[f];  // "double product = lambda[j]", :70
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) pre[k + 1][f] = pre[k][f] + a[k][f];
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) g[f] = pre[D][f];
+    float suf[FPL];
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k)
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) {
+            const float ak = a[k][f];
+            if (k == D - 1) {
+                a[k][f] = pre[k][f];
+                suf[f] = ak;
+            } else {
+                a[k][f] = pre[k][f] + suf[f];
+                suf[f] = ak + suf[f];
+            }
+        }
+}
+
+template <int FPL, int D>
+__device__ __forceinline__ void vn_col(float* msg, const float* lamrow, const int* edges, int T, bool write_beta,
+                                       float (&g)[FPL]) {
+    float lam[FPL];
+    ldv<FPL>(lamrow, lam);
+    if constexpr (D == 0) {
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) g[f] = lam[f];
+    } else {
+        float a[D][FPL];
+        long long off[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) off[k] = (long long)edges[k] * T;
+#pragma unroll
+        for (int k = 0; k < D; ++k) ldv<FPL>(msg + off[k], a[k]);
+        vn_compute<FPL, D>(a, lam, g);
+        if (write_beta) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) stv<FPL>(msg + off[k], a[k]);
+        }
+    }
+}
+
+__device__ __forceinline__ float vn_col_lds(float* msg, const float* lamrow, const int* edges, int T, int d,
+                                            bool write_beta, float* lds, int cap, int lane) {
+    float* sa = lds + lane;                        // alpha
+    float* sp = lds + (long long)cap * 64 + lane;  // prefix sums
+    float pre = lamrow[0];
+    for (int k = 0; k < d; ++k) {
+        const float a = msg[(long long)edges[k] * T];
+        sa[k * 64] = a;
+        sp[k * 64] = pre;
+        pre += a;
+    }
+    if (write_beta) {
+        float suf = 0.0f;
+        for (int k = d - 1; k >= 0; --k) {
+            const float a = sa[k * 64];
+            msg[(long long)edges[k] * T] = (k == d - 1) ? sp[k * 64] : (sp[k * 64] + suf);
+            suf = (k == d - 1) ? a : (a + suf);
+        }
+    }
+    return pre;
+}
+
+// ---- degree dispatch -------------------------------------------------------------------
+#define LDPC_CASE_CN(D)                                                              \
+    case D:                                                                          \
+        if constexpr (D <= (FPL == 1 ? kRegDegFpl1 : kRegDegFpl4))                   \
+            cn_row<FPL, D, RULE, FIRST>(row, lam, cols, T);                          \
+        else if constexpr (FPL == 1)                                                 \
+            cn_row_lds<RULE, FIRST>(row, lam, cols, T, d, lds, cap, lane);           \
+        break;
+#define LDPC_CASE_VN(D)                                                              \
+    case D:                                                                          \
+        if constexpr (D <= (FPL == 1 ? kRegDegFpl1 : kRegDegFpl4))                   \
+            vn_col<FPL, D>(msg, lamrow, edges, T, write_beta, g);                    \
+        else if constexpr (FPL == 1)                                                 \
+            g[0] = vn_col_lds(msg, lamrow, edges, T, d, write_beta, lds, cap, lane); \
+        break;
+
+template <int FPL, int RULE, bool FIRST>
+__device__ __forceinline__ void cn_dispatch(int d, float* row, const float* lam, const int* cols, int T, float* lds,
+                                            int cap, int lane) {
+    switch (d) {
+        case 0: break;
+        LDPC_CASE_CN(1) LDPC_CASE_CN(2) LDPC_CASE_CN(3) LDPC_CASE_CN(4)
+        LDPC_CASE_CN(5) LDPC_CASE_CN(6) LDPC_CASE_CN(7) LDPC_CASE_CN(8)
+        default:
+            if constexpr (FPL == 1) {
+                switch (d) {
+                    LDPC_CASE_CN(9) LDPC_CASE_CN(10) LDPC_CASE_CN(11) LDPC_CASE_CN(12)
+                    LDPC_CASE_CN(13) LDPC_CASE_CN(14) LDPC_CASE_CN(15) LDPC_CASE_CN(16)
+                    LDPC_CASE_CN(17) LDPC_CASE_CN(18) LDPC_CASE_CN(19) LDPC_CASE_CN(20)
+                    LDPC_CASE_CN(21) LDPC_CASE_CN(22) LDPC_CASE_CN(23) LDPC_CASE_CN(24)
+                    LDPC_CASE_CN(25) LDPC_CASE_CN(26) LDPC_CASE_CN(27) LDPC_CASE_CN(28)
+                    LDPC_CASE_CN(29) LDPC_CASE_CN(30) LDPC_CASE_CN(31) LDPC_CASE_CN(32)
+                    default: cn_row_lds<RULE, FIRST>(row, lam, cols, T, d, lds, cap, lane); break;
+                }
+            }
+            break;
+    }
+}
+
+template <int FPL>
+__device__ __forceinline__ void vn_dispatch(int d, float* msg, const float* lamrow, const int* edges, int T,
+                                            bool write_beta, float (&g)[FPL], float* lds, int cap, int lane) {
+    switch (d) {
+        LDPC_CASE_VN(0) LDPC_CASE_VN(1) LDPC_CASE_VN(2) LDPC_CASE_VN(3) LDPC_CASE_VN(4)
+        LDPC_CASE_VN(5) LDPC_CASE_VN(6) LDPC_CASE_VN(7) LDPC_CASE_VN(8)
+        default:
+            if constexpr (FPL == 1) {
+                switch (d) {
+                    LDPC_CASE_VN(9) LDPC_CASE_VN(10) LDPC_CASE_VN(11) LDPC_CASE_VN(12)
+                    LDPC_CASE_VN(13) LDPC_CASE_VN(14) LDPC_CASE_VN(15) LDPC_CASE_VN(16)
+                    LDPC_CASE_VN(17) LDPC_CASE_VN(18) LDPC_CASE_VN(19) LDPC_CASE_VN(20)
+                    LDPC_CASE_VN(21) LDPC_CASE_VN(22) LDPC_CASE_VN(23) LDPC_CASE_VN(24)
+                    LDPC_CASE_VN(25) LDPC_CASE_VN(26) LDPC_CASE_VN(27) LDPC_CASE_VN(28)
+                    LDPC_CASE_VN(29) LDPC_CASE_VN(30) LDPC_CASE_VN(31) LDPC_CASE_VN(32)
+                    default: g[0] = vn_col_lds(msg, lamrow, edges, T, d, write_beta, lds, cap, lane); break;
+                }
+            }
+            break;
+    }
+}
+#undef LDPC_CASE_CN
+#undef LDPC_CASE_VN
+
+// ---- sweeps ------------------------------------------------------------------------------
+template <int FPL, int RULE, bool FIRST>
+__device__ __forceinline__ void cn_sweep(const BpParams& p, float* msg, const float* lam, int T, float* lds, int lane) {
+    for (int i = 0; i < p.m; ++i) {
+        const int e0 = p.row_ptr[i];
+        const int d = p.row_ptr[i + 1] - e0;
+        cn_dispatch<FPL, RULE, FIRST>(d, msg + (long long)e0 * T, lam, p.edge_col + e0, T, lds, p.lds_maxd, lane);
+    }
+}
+
+// beta for the next iteration + tentative decisions of this one (LogDecoder.java:67-79, :98-105)
+template <int FPL>
+__device__ __forceinline__ void vn_sweep(const BpParams& p, float* msg, const float* lam, uint32_t* bits, int T,
+                                         bool write_beta, float* lds, int lane) {
+    uint32_t acc[FPL];
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) acc[f] = 0u;
+    for (int j = 0; j < p.n; ++j) {
+        const int c0 = p.col_ptr[j];
+        const int d = p.col_ptr[j + 1] - c0;
+        float g[FPL];
+        vn_dispatch<FPL>(d, msg, lam + (long long)j * T, p.col_edge + c0, T, write_beta, g, lds, p.lds_maxd, lane);
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) acc[f] |= (g[f] < 0.0f ? 1u : 0u) << (j & 31);  // "(gamma[j] < 0) ? 1 : 0", :104
+        if ((j & 31) == 31 || j == p.n - 1) {
+            stw<FPL>(bits + (long long)(j >> 5) * T, acc);
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) acc[f] = 0u;
+        }
+    }
+}
+
+// number of unsatisfied checks of the packed decisions (sumSyndro, LogDecoder.java:108-116)
+template <int FPL>
+__device__ __forceinline__ void syndrome_sweep(const BpParams& p, const uint32_t* bits, int T, int (&w)[FPL]) {
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) w[f] = 0;
+    for (int i = 0; i < p.m; ++i) {
+        const int e0 = p.row_ptr[i], e1 = p.row_ptr[i + 1];
+        uint32_t par[FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) par[f] = 0u;
+        for (int e = e0; e < e1; ++e) {
+            const int j = p.edge_col[e];
+            uint32_t v[FPL];
+            ldw<FPL>(bits + (long long)(j >> 5) * T, v);
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) par[f] ^= v[f] >> (j & 31);
+        }
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) w[f] += (int)(par[f] & 1u);
+    }
+}
+
+// ---- the decoder: one wave = one tile, all iterations in one launch -------------------------
+template <int FPL, int RULE, bool EARLY>
+__global__ void __launch_bounds__(256, 4) bp_decode_kernel(BpParams p) {
+    extern __shared__ float lds_all[];
+    static_assert(!EARLY || FPL == 1, "per-frame early termination masks whole lanes");
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = threadIdx.x >> 6;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    if (tile >= p.tiles) return;
+    constexpr int T = kWave * FPL;
+    float* lds = lds_all + (long long)wave_in_block * 2 * p.lds_maxd * 64;
+    float* msg = p.ws_msg + (long long)tile * p.msg_stride + lane * FPL;
+    const float* lam = p.ws_lam + (long long)tile * p.lam_stride + lane * FPL;
+    uint32_t* bits = p.ws_bits + (long long)tile * p.bits_stride + lane * FPL;
+    const long long frame0 = p.frame_base + (long long)tile * T + lane * FPL;
+
+    if constexpr (EARLY) {
+        bool active = frame0 < p.frames_total;
+        int iters = p.max_iters, synd = 0;
+        for (int it = 0; it < p.max_iters; ++it) {
+            if (active) {
+                if (it == 0) cn_sweep<FPL, RULE, true>(p, msg, lam, T, lds, lane);
+                else         cn_sweep<FPL, RULE, false>(p, msg, lam, T, lds, lane);
+                vn_sweep<FPL>(p, msg, lam, bits, T, true, lds, lane);
+                int w[1];
+                syndrome_sweep<1>(p, bits, T, w);
+                synd = w[0];
+                if (synd == 0) {  // "if(sumSyndro == 0) return ... l + 1", LogDecoder.java:117-119
+                    iters = it + 1;
+                    active = false;
+                }
+            }
+            if (__ballot(active) == 0ull) break;
+        }
+        if (frame0 < p.frames_total) {
+            if (p.out_iters) p.out_iters[frame0] = iters;
+            if (p.out_synd) p.out_synd[frame0] = synd;
+        }
+    } else {
+        for (int it = 0; it < p.max_iters; ++it) {
+            if (it == 0) cn_sweep<FPL, RULE, true>(p, msg, lam, T, lds, lane);
+            else         cn_sweep<FPL, RULE, false>(p, msg, lam, T, lds, lane);
+            vn_sweep<FPL>(p, msg, lam, bits, T, it + 1 < p.max_iters, lds, lane);
+        }
+        int w[FPL];
+        syndrome_sweep<FPL>(p, bits, T, w);
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) {
+            if (frame0 + f < p.frames_total) {
+                if (p.out_iters) p.out_iters[frame0 + f] = p.max_iters;
+                if (p.out_synd) p.out_synd[frame0 + f] = w[f];
+            }
+        }
+    }
+}
+
+}  // namespace ldpc

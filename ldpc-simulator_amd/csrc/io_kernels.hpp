@@ -1,0 +1,201 @@
+// Layout changes around the decoder, the on-device channel and the error accounting.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.hpp"
+
+namespace ldpc {
+
+// ---- frame-row input -> frame-major lambda tiles ---------------------------------------------
+// in[frame][j] (row per frame, what a caller holds) becomes lam[tile][j][t], t = frame % T:
+// the layout in which lane t of a wave reads its own frame with one coalesced row per j.
+// A 64 x 64 block goes through LDS (row stride 65 words, conflict-free both ways).
+struct FloatLlr {
+    const float* in;
+    __device__ float operator()(long long idx, int /*j*/) const { return in[idx]; }
+};
+// lambda from a hard received word: LogDecoder.java:45-54 / LogDecoderBefore.java:45-50
+struct BscLlr {
+    const uint8_t* in;
+    float l0, l1;
+    int g_length;  // n - m, LogDecoder.java:24
+    __device__ float operator()(long long idx, int j) const {
+        const float mag = (j < g_length) ? l0 : l1;
+        return (in[idx] == 0) ? mag : -mag;
+    }
+};
+
+template <class Src>
+__global__ void __launch_bounds__(256) load_lambda_kernel(Src src, float* ws_lam, long long lam_stride, int n, int T,
+                                                          long long frame_base, long long frames_total) {
+    __shared__ float tile[64][65];
+    const int chunks_per_tile = T >> 6;
+    const int tile_id = blockIdx.x / chunks_per_tile;
+    const int t0 = (blockIdx.x % chunks_per_tile) << 6;
+    const int j0 = blockIdx.y << 6;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long f0 = frame_base + (long long)tile_id * T + t0;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int fr = ty * 16 + r;
+        const long long frame = f0 + fr;
+        const int j = j0 + tx;
+        float v = 0.0f;
+        if (frame < frames_total && j < n) v = src(frame * n + j, j);
+        tile[fr][tx] = v;
+    }
+    __syncthreads();
+    float* out = ws_lam + (long long)tile_id * lam_stride;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int jj = ty * 16 + r;
+        const int j = j0 + jj;
+        if (j < n) out[(long long)j * T + t0 + tx] = tile[tx][jj];
+    }
+}
+
+// ---- packed decisions -> hard[frame][j] bytes ---------------------------------------------------
+__global__ void __launch_bounds__(256) unpack_hard_kernel(const uint32_t* ws_bits, long long bits_stride, int n, int T,
+                                                          long long frame_base, long long frames_in_launch,
+                                                          uint8_t* hard) {
+    const int n4 = (n + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long fl = idx / n4;  // frame within the launch
+    if (fl >= frames_in_launch) return;
+    const int j = (int)(idx % n4) << 2;
+    const long long tile = fl / T;
+    const int t = (int)(fl % T);
+    const uint32_t w = ws_bits[tile * bits_stride + (long long)(j >> 5) * T + t] >> (j & 31);
+    uint8_t* o = hard + (frame_base + fl) * n + j;
+    if ((n & 3) == 0) {
+        *reinterpret_cast<uchar4*>(o) = make_uchar4(w & 1u, (w >> 1) & 1u, (w >> 2) & 1u, (w >> 3) & 1u);
+    } else {
+        for (int k = 0; k < 4 && j + k < n; ++k) o[k] = (uint8_t)((w >> k) & 1u);
+    }
+}
+
+// ---- channel: all-zero codeword -------------------------------------------------------------------
+// Channel.java:5-17 / :28-39: "random.nextDouble() < e" becomes u32 < floor(e * 2^32) on one
+// Philox word per position; positions >= flip_end are copied unchanged (error-free parity part).
+__global__ void __launch_bounds__(256) gen_bsc_kernel(int n, int flip_end, uint32_t thr, uint64_t seed,
+                                                      long long first_frame, long long frames, uint8_t* r) {
+    const int n4 = (n + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long f = idx / n4;
+    if (f >= frames) return;
+    const int g = (int)(idx % n4);
+    const int j = g << 2;
+    const u32x4 x = frame_block(seed, (uint64_t)(first_frame + f), (uint32_t)g, 0u);
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+    uint8_t b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = (j + k < flip_end && xs[k] < thr) ? 1 : 0;
+    uint8_t* o = r + f * n + j;
+    if ((n & 3) == 0) {
+        *reinterpret_cast<uchar4*>(o) = make_uchar4(b[0], b[1], b[2], b[3]);
+    } else {
+        for (int k = 0; k < 4 && j + k < n; ++k) o[k] = b[k];
+    }
+}
+
+// BPSK over AWGN, all-zero codeword (+1 sent): llr = 2*y/sigma^2 = a + b*z, a = 2/sigma^2,
+// b = 2/sigma, z ~ N(0,1) by Box-Muller on two Philox words per pair of positions.
+__global__ void __launch_bounds__(256) gen_awgn_kernel(int n, float a, float b, uint64_t seed, long long first_frame,
+                                                       long long frames, float* llr) {
+    const int n4 = (n + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long f = idx / n4;
+    if (f >= frames) return;
+    const int g = (int)(idx % n4);
+    const int j = g << 2;
+    const u32x4 x = frame_block(seed, (uint64_t)(first_frame + f), (uint32_t)g, 1u);
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)xs[2 * h] + 0.5f) * 2.3283064365386963e-10f;
+        const float u2 = (float)xs[2 * h + 1] * 2.3283064365386963e-10f;
+        const float rad = sqrtf(-2.0f * logf(u1));
+        const float th = 6.283185307179586f * u2;
+        z[2 * h] = rad * cosf(th);
+        z[2 * h + 1] = rad * sinf(th);
+    }
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = a + b * z[k];
+    float* o = llr + f * n + j;
+    if ((n & 3) == 0) {
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        for (int k = 0; k < 4 && j + k < n; ++k) o[k] = v[k];
+    }
+}
+
+// ---- error accounting (LDPC_GallagerIntStreamSimu.java:136-183, c = all-zero) -------------------------
+// One wave per frame at a time, lanes stride the positions; a block handles 64 frames and keeps its
+// sums in LDS so that each block issues at most (16 + max_iters) global atomics.
+struct RxNone { __device__ int operator()(long long) const { return 0; } };
+struct RxBytes { const uint8_t* p; __device__ int operator()(long long i) const { return p[i] != 0; } };
+struct RxLlrSign { const float* p; __device__ int operator()(long long i) const { return p[i] < 0.0f; } };
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <class Rx, bool HAS_RX>
+__global__ void __launch_bounds__(256) count_errors_kernel(int n, int k_info, long long frames, const uint8_t* hard, Rx rx,
+                                                           const int32_t* iters, const int32_t* synd, int max_iters,
+                                                           unsigned long long* counters) {
+    extern __shared__ unsigned long long acc[];  // 16 + max_iters
+    const int nc = 16 + max_iters;
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) acc[i] = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long fb = (long long)blockIdx.x * 64;
+    for (int q = wave; q < 64; q += 4) {
+        const long long f = fb + q;
+        if (f >= frames) break;
+        unsigned info = 0, chk = 0, mis = 0, ch = 0;
+        const uint8_t* d = hard + f * n;
+        for (int j = lane; j < n; j += 64) {
+            const unsigned dj = d[j] != 0;
+            if (j < k_info) {
+                info += dj;
+                if (HAS_RX) {
+                    const unsigned rj = (unsigned)rx(f * n + j);
+                    ch += rj;
+                    mis += (rj == 0u && dj) ? 1u : 0u;
+                }
+            } else {
+                chk += dj;
+            }
+        }
+        info = wave_sum(info); chk = wave_sum(chk); mis = wave_sum(mis); ch = wave_sum(ch);
+        if (lane == 0) {
+            const bool correct = (info + chk) == 0;
+            const int it = iters[f];
+            atomicAdd(&acc[0], 1ull);
+            if (!correct) atomicAdd(&acc[1], 1ull);
+            if (info) { atomicAdd(&acc[2], (unsigned long long)info); atomicAdd(&acc[4], 1ull); }
+            if (chk) { atomicAdd(&acc[3], (unsigned long long)chk); atomicAdd(&acc[5], 1ull); }
+            if (synd[f] == 0 && !correct) atomicAdd(&acc[6], 1ull);
+            if (HAS_RX) {
+                if (mis) atomicAdd(&acc[7], (unsigned long long)mis);
+                if (ch) {
+                    atomicAdd(&acc[10], (unsigned long long)ch);
+                    atomicAdd(&acc[11], (unsigned long long)ch * ch);
+                }
+            }
+            atomicAdd(&acc[correct ? 8 : 9], (unsigned long long)it);
+            if (it >= 1 && it <= max_iters) atomicAdd(&acc[16 + it - 1], 1ull);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc; i += blockDim.x)
+        if (acc[i]) atomicAdd(&counters[i], acc[i]);
+}
+
+}  // namespace ldpc

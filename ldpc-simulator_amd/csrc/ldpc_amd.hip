@@ -1,0 +1,619 @@
+// C ABI of the gfx950 belief-propagation decoder (declared in include/ldpc_amd.h).
+// Host side: Tanner-graph construction, workspace and launch sequencing.  No CPU decode
+// path exists in this library: without a HIP device every compute entry point fails.
+#include "../../include/ldpc_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bp_kernels.hpp"
+#include "io_kernels.hpp"
+
+using namespace ldpc;
+
+struct ldpc_amd_ctx {
+    int device = 0;
+    int m = 0, n = 0, nw = 0;
+    long long E = 0;
+    int max_dc = 0, max_dv = 0;
+    int cn_rule = LDPC_AMD_CN_SUMPRODUCT;
+    int* d_row_ptr = nullptr;
+    int* d_edge_col = nullptr;
+    int* d_col_ptr = nullptr;
+    int* d_col_edge = nullptr;
+    std::vector<int> h_row_ptr, h_edge_col, h_col_ptr, h_col_edge;
+    // decode workspace: [tiles][E][T] messages | [tiles][n][T] lambda | [tiles][nw][T] decisions
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    unsigned long long ws_limit = 0;
+    // staging for the host-pointer entry points and for simulate
+    void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[4] = {0, 0, 0, 0};
+    unsigned long long* d_counters = nullptr;
+    size_t counters_len = 0;
+    // timing of the last decode
+    std::vector<hipEvent_t> ev;
+    int timed_launches = 0;
+    long long timed_frames = 0;
+    hipStream_t timed_stream = nullptr;
+    std::string err;
+};
+
+namespace {
+
+std::mutex g_err_mutex;
+std::string g_create_err;
+
+int fail(ldpc_amd_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) {
+        ctx->err = msg;
+    } else {
+        std::lock_guard<std::mutex> lk(g_err_mutex);
+        g_create_err = msg;
+    }
+    return code;
+}
+
+#define LDPC_HIP(ctx, call)                                                                          \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? LDPC_AMD_ENOMEM : LDPC_AMD_EHIP,            \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                          \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess) ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+// A(i) / B(j) as the row-major scan of LogDecoder.java:35-42 produces them: ascending.
+// Out-of-range pairs are dropped and repeats collapse (CheckMatrixIO.java:37-45).
+void build_graph(ldpc_amd_ctx* c, long long nnz, const int32_t* rows, const int32_t* cols) {
+    const int m = c->m, n = c->n;
+    std::vector<long long> key;
+    key.reserve((size_t)nnz);
+    for (long long t = 0; t < nnz; ++t) {
+        const long long r = rows[t], q = cols[t];
+        if (r < 0 || r >= m || q < 0 || q >= n) continue;
+        key.push_back(r * (long long)n + q);
+    }
+    std::sort(key.begin(), key.end());
+    key.erase(std::unique(key.begin(), key.end()), key.end());
+    const long long E = (long long)key.size();
+    c->E = E;
+    c->h_row_ptr.assign((size_t)m + 1, 0);
+    c->h_col_ptr.assign((size_t)n + 1, 0);
+    c->h_edge_col.resize((size_t)E);
+    c->h_col_edge.resize((size_t)E);
+    for (long long e = 0; e < E; ++e) {
+        const int r = (int)(key[(size_t)e] / n), q = (int)(key[(size_t)e] % n);
+        c->h_edge_col[(size_t)e] = q;
+        c->h_row_ptr[(size_t)r + 1]++;
+        c->h_col_ptr[(size_t)q + 1]++;
+    }
+    for (int i = 0; i < m; ++i) c->h_row_ptr[(size_t)i + 1] += c->h_row_ptr[(size_t)i];
+    for (int j = 0; j < n; ++j) c->h_col_ptr[(size_t)j + 1] += c->h_col_ptr[(size_t)j];
+    std::vector<int> fill(c->h_col_ptr.begin(), c->h_col_ptr.end() - 1);
+    for (long long e = 0; e < E; ++e) c->h_col_edge[(size_t)fill[(size_t)c->h_edge_col[(size_t)e]]++] = (int)e;
+    c->max_dc = c->max_dv = 0;
+    for (int i = 0; i < m; ++i) c->max_dc = std::max(c->max_dc, c->h_row_ptr[(size_t)i + 1] - c->h_row_ptr[(size_t)i]);
+    for (int j = 0; j < n; ++j) c->max_dv = std::max(c->max_dv, c->h_col_ptr[(size_t)j + 1] - c->h_col_ptr[(size_t)j]);
+}
+
+int ensure_stage(ldpc_amd_ctx* c, int slot, size_t bytes) {
+    if (c->stage_bytes[slot] >= bytes) return LDPC_AMD_OK;
+    if (c->stage[slot]) {
+        LDPC_HIP(c, hipFree(c->stage[slot]));
+        c->stage[slot] = nullptr;
+        c->stage_bytes[slot] = 0;
+    }
+    LDPC_HIP(c, hipMalloc(&c->stage[slot], bytes));
+    c->stage_bytes[slot] = bytes;
+    return LDPC_AMD_OK;
+}
+
+constexpr int kLdsMaxDegree = 128;  // 2 arrays x 128 rows x 256 B = 64 KiB per wave
+
+enum class Src { Float, Bsc };
+
+struct SrcArgs {
+    Src kind;
+    const float* llr;
+    const uint8_t* r;
+    float l0, l1;
+};
+
+template <int FPL>
+int launch_bp(ldpc_amd_ctx* c, const BpParams& p, bool early, int wpb, size_t lds_bytes, hipStream_t s) {
+    const dim3 grid((unsigned)((p.tiles + wpb - 1) / wpb)), block((unsigned)(64 * wpb));
+    const bool ms = c->cn_rule == LDPC_AMD_CN_MINSUM;
+    if constexpr (FPL == 1) {
+        if (early) {
+            if (ms) hipLaunchKernelGGL((bp_decode_kernel<1, kCnMinSum, true>), grid, block, lds_bytes, s, p);
+            else    hipLaunchKernelGGL((bp_decode_kernel<1, kCnSumProduct, true>), grid, block, lds_bytes, s, p);
+        } else {
+            if (ms) hipLaunchKernelGGL((bp_decode_kernel<1, kCnMinSum, false>), grid, block, lds_bytes, s, p);
+            else    hipLaunchKernelGGL((bp_decode_kernel<1, kCnSumProduct, false>), grid, block, lds_bytes, s, p);
+        }
+    } else {
+        if (ms) hipLaunchKernelGGL((bp_decode_kernel<FPL, kCnMinSum, false>), grid, block, lds_bytes, s, p);
+        else    hipLaunchKernelGGL((bp_decode_kernel<FPL, kCnSumProduct, false>), grid, block, lds_bytes, s, p);
+    }
+    LDPC_HIP(c, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_iters, int early_term, uint8_t* d_hard,
+               int32_t* d_iters, int32_t* d_synd, hipStream_t s) {
+    if (frames < 0 || max_iters < 0 || !d_hard) return fail(c, LDPC_AMD_EINVAL, "decode: bad argument");
+    c->timed_launches = 0;
+    c->timed_frames = 0;
+    c->timed_stream = s;
+    if (frames == 0) return LDPC_AMD_OK;
+    const int n = c->n;
+    if (max_iters == 0) {  // maxL = 0: all-zero word, 0 iterations, syndrome 0 (LogDecoder.java:61, :122)
+        LDPC_HIP(c, hipMemsetAsync(d_hard, 0, (size_t)frames * n, s));
+        if (d_iters) LDPC_HIP(c, hipMemsetAsync(d_iters, 0, (size_t)frames * 4, s));
+        if (d_synd) LDPC_HIP(c, hipMemsetAsync(d_synd, 0, (size_t)frames * 4, s));
+        return LDPC_AMD_OK;
+    }
+    const int maxdeg = std::max(c->max_dc, c->max_dv);
+    if (maxdeg > kLdsMaxDegree) return fail(c, LDPC_AMD_ELIMIT, "node degree above 128 is not supported");
+    const bool early = early_term != 0;
+    int fpl = (!early && maxdeg <= kRegDegFpl4) ? 4 : 1;
+    if (const char* env = getenv("LDPC_AMD_FPL")) {
+        const int v = atoi(env);
+        if (!early && maxdeg <= kRegDegFpl4 && (v == 1 || v == 2 || v == 4)) fpl = v;
+    }
+    const int T = 64 * fpl;
+    const bool use_lds = maxdeg > kRegDegFpl1;
+    const int lds_maxd = use_lds ? maxdeg : 0;
+    const int wpb = use_lds ? 1 : 4;
+    const size_t lds_bytes = use_lds ? (size_t)2 * lds_maxd * 64 * sizeof(float) : 0;
+
+    const long long tiles_total = (frames + T - 1) / T;
+    const size_t per_tile = ((size_t)c->E + (size_t)n + (size_t)c->nw) * T * sizeof(float);
+    unsigned long long limit = c->ws_limit;
+    if (!limit) {
+        size_t fr = 0, tot = 0;
+        LDPC_HIP(c, hipMemGetInfo(&fr, &tot));
+        limit = (unsigned long long)((double)(fr + c->ws_bytes) * 0.6);
+    }
+    long long max_tiles = (long long)(limit / per_tile);
+    if (max_tiles < 1) max_tiles = 1;
+    if (max_tiles > (1ll << 30)) max_tiles = 1ll << 30;
+    const long long rounds = (tiles_total + max_tiles - 1) / max_tiles;
+    const long long tiles_per_round = (tiles_total + rounds - 1) / rounds;
+    const size_t need = per_tile * (size_t)tiles_per_round;
+    if (c->ws_bytes < need) {
+        if (c->ws) {
+            LDPC_HIP(c, hipFree(c->ws));
+            c->ws = nullptr;
+            c->ws_bytes = 0;
+        }
+        LDPC_HIP(c, hipMalloc(&c->ws, need));
+        c->ws_bytes = need;
+    }
+    while ((long long)c->ev.size() < 2 * std::min<long long>(rounds, 256)) {
+        hipEvent_t e;
+        LDPC_HIP(c, hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+
+    BpParams p{};
+    p.m = c->m; p.n = n; p.nw = c->nw;
+    p.row_ptr = c->d_row_ptr; p.edge_col = c->d_edge_col; p.col_ptr = c->d_col_ptr; p.col_edge = c->d_col_edge;
+    p.msg_stride = c->E * T; p.lam_stride = (long long)n * T; p.bits_stride = (long long)c->nw * T;
+    float* ws_msg = (float*)c->ws;
+    float* ws_lam = ws_msg + (size_t)tiles_per_round * p.msg_stride;
+    uint32_t* ws_bits = (uint32_t*)(ws_lam + (size_t)tiles_per_round * p.lam_stride);
+    p.ws_msg = ws_msg; p.ws_lam = ws_lam; p.ws_bits = ws_bits;
+    p.frames_total = frames; p.max_iters = max_iters;
+    p.out_iters = d_iters; p.out_synd = d_synd;
+    p.lds_maxd = lds_maxd;
+
+    for (long long r = 0; r < rounds; ++r) {
+        const long long tile0 = r * tiles_per_round;
+        const int tiles = (int)std::min<long long>(tiles_per_round, tiles_total - tile0);
+        const long long frame_base = tile0 * T;
+        const long long frames_here = std::min<long long>((long long)tiles * T, frames - frame_base);
+        p.tiles = tiles;
+        p.frame_base = frame_base;
+        {
+            const dim3 grid((unsigned)(tiles * (T / 64)), (unsigned)((n + 63) / 64)), block(256);
+            if (src.kind == Src::Float) {
+                hipLaunchKernelGGL((load_lambda_kernel<FloatLlr>), grid, block, 0, s, FloatLlr{src.llr}, ws_lam,
+                                   p.lam_stride, n, T, frame_base, frames);
+            } else {
+                hipLaunchKernelGGL((load_lambda_kernel<BscLlr>), grid, block, 0, s,
+                                   BscLlr{src.r, src.l0, src.l1, n - c->m}, ws_lam, p.lam_stride, n, T, frame_base,
+                                   frames);
+            }
+            LDPC_HIP(c, hipGetLastError());
+        }
+        const bool timed = r < 256;
+        if (timed) LDPC_HIP(c, hipEventRecord(c->ev[(size_t)(2 * r)], s));
+        int rc;
+        if (fpl == 4) rc = launch_bp<4>(c, p, early, wpb, lds_bytes, s);
+        else if (fpl == 2) rc = launch_bp<2>(c, p, early, wpb, lds_bytes, s);
+        else rc = launch_bp<1>(c, p, early, wpb, lds_bytes, s);
+        if (rc) return rc;
+        if (timed) {
+            LDPC_HIP(c, hipEventRecord(c->ev[(size_t)(2 * r + 1)], s));
+            c->timed_launches++;
+            c->timed_frames += frames_here;
+        }
+        {
+            const long long n4 = (n + 3) / 4;
+            const long long threads = frames_here * n4;
+            const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+            hipLaunchKernelGGL(unpack_hard_kernel, grid, block, 0, s, ws_bits, p.bits_stride, n, T, frame_base,
+                               frames_here, d_hard);
+            LDPC_HIP(c, hipGetLastError());
+        }
+    }
+    return LDPC_AMD_OK;
+}
+
+int bsc_magnitudes(ldpc_amd_ctx* c, double e, int llr_mode, float* l0, float* l1) {
+    if (!(e > 0.0) || !(e < 1.0)) return fail(c, LDPC_AMD_EINVAL, "crossover probability must be in (0,1)");
+    const double d0 = std::log((1 - e) / e);  // LogDecoder.java:46
+    double d1 = d0;
+    if (llr_mode == LDPC_AMD_LLR_PARITY_LN1E20) d1 = std::log((1 - 0.00000000000000000001) / 0.00000000000000000001);
+    else if (llr_mode == LDPC_AMD_LLR_PARITY_1EM7) d1 = std::log((1 - 0.0000001) / 0.0000001);
+    else if (llr_mode != LDPC_AMD_LLR_UNIFORM) return fail(c, LDPC_AMD_EINVAL, "unknown llr_mode");
+    *l0 = (float)d0;
+    *l1 = (float)d1;
+    return LDPC_AMD_OK;
+}
+
+uint32_t bsc_threshold(double e) {
+    if (!(e > 0.0)) return 0u;
+    const double t = std::floor(e * 4294967296.0);
+    return (t >= 4294967295.0) ? 4294967295u : (uint32_t)t;
+}
+
+int count_launch(ldpc_amd_ctx* c, long long frames, const uint8_t* d_hard, const uint8_t* d_rx, const float* d_rx_llr,
+                 const int32_t* d_iters, const int32_t* d_synd, int max_iters, unsigned long long* d_counters,
+                 hipStream_t s) {
+    if (frames <= 0) return LDPC_AMD_OK;
+    const dim3 grid((unsigned)((frames + 63) / 64)), block(256);
+    const size_t sh = (size_t)(16 + max_iters) * sizeof(unsigned long long);
+    const int k = c->n - c->m;
+    if (d_rx) {
+        hipLaunchKernelGGL((count_errors_kernel<RxBytes, true>), grid, block, sh, s, c->n, k, frames, d_hard,
+                           RxBytes{d_rx}, d_iters, d_synd, max_iters, d_counters);
+    } else if (d_rx_llr) {
+        hipLaunchKernelGGL((count_errors_kernel<RxLlrSign, true>), grid, block, sh, s, c->n, k, frames, d_hard,
+                           RxLlrSign{d_rx_llr}, d_iters, d_synd, max_iters, d_counters);
+    } else {
+        hipLaunchKernelGGL((count_errors_kernel<RxNone, false>), grid, block, sh, s, c->n, k, frames, d_hard, RxNone{},
+                           d_iters, d_synd, max_iters, d_counters);
+    }
+    LDPC_HIP(c, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+int gen_bsc(ldpc_amd_ctx* c, int channel, double e, uint64_t seed, long long first_frame, long long frames,
+            uint8_t* d_r, hipStream_t s) {
+    if (channel != LDPC_AMD_CH_BSC_INFO && channel != LDPC_AMD_CH_BSC_ALL)
+        return fail(c, LDPC_AMD_EINVAL, "gen_bsc: channel must be a BSC channel");
+    if (frames <= 0) return LDPC_AMD_OK;
+    const int flip_end = (channel == LDPC_AMD_CH_BSC_INFO) ? (c->n - c->m) : c->n;
+    const long long threads = frames * ((c->n + 3) / 4);
+    hipLaunchKernelGGL(gen_bsc_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, c->n, flip_end,
+                       bsc_threshold(e), seed, first_frame, frames, d_r);
+    LDPC_HIP(c, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+int gen_awgn(ldpc_amd_ctx* c, double ebn0_db, uint64_t seed, long long first_frame, long long frames, float* d_llr,
+             hipStream_t s) {
+    if (frames <= 0) return LDPC_AMD_OK;
+    if (c->n <= c->m) return fail(c, LDPC_AMD_EINVAL, "gen_awgn: code rate (n-m)/n must be positive");
+    const double rate = (double)(c->n - c->m) / (double)c->n;
+    const double sigma2 = 1.0 / (2.0 * rate * std::pow(10.0, ebn0_db / 10.0));
+    const float a = (float)(2.0 / sigma2), b = (float)(2.0 / std::sqrt(sigma2));
+    const long long threads = frames * ((c->n + 3) / 4);
+    hipLaunchKernelGGL(gen_awgn_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, c->n, a, b, seed,
+                       first_frame, frames, d_llr);
+    LDPC_HIP(c, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ldpc_amd_version(void) { return LDPC_AMD_VERSION; }
+
+const char* ldpc_amd_last_error(const ldpc_amd_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_create_err;
+    return copy.c_str();
+}
+
+int ldpc_amd_create(int32_t m, int32_t n, int64_t nnz, const int32_t* row_idx, const int32_t* col_idx,
+                    int32_t device_id, ldpc_amd_ctx** out) {
+    if (!out) return fail(nullptr, LDPC_AMD_EINVAL, "create: out is null");
+    *out = nullptr;
+    if (m < 0 || n <= 0 || nnz < 0 || (nnz > 0 && (!row_idx || !col_idx)))
+        return fail(nullptr, LDPC_AMD_EINVAL, "create: bad matrix shape or null index arrays");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LDPC_AMD_ENODEV, "create: no HIP device (this library has no CPU path)");
+    int dev = device_id;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(nullptr, LDPC_AMD_ENODEV, "create: hipGetDevice failed");
+    if (dev >= ndev) return fail(nullptr, LDPC_AMD_EINVAL, "create: device_id out of range");
+    ldpc_amd_ctx* c = new (std::nothrow) ldpc_amd_ctx();
+    if (!c) return fail(nullptr, LDPC_AMD_ENOMEM, "create: out of host memory");
+    c->device = dev;
+    c->m = m; c->n = n; c->nw = (n + 31) / 32;
+    build_graph(c, nnz, row_idx, col_idx);
+    DeviceGuard guard(dev);
+    auto bail = [&](int code, const std::string& msg) {
+        fail(nullptr, code, msg);
+        ldpc_amd_destroy(c);
+        return code;
+    };
+    if (!guard.ok) return bail(LDPC_AMD_EHIP, "create: hipSetDevice failed");
+    const size_t eb = (size_t)std::max<long long>(c->E, 1) * sizeof(int);
+    hipError_t e;
+    if ((e = hipMalloc((void**)&c->d_row_ptr, ((size_t)m + 1) * sizeof(int))) != hipSuccess ||
+        (e = hipMalloc((void**)&c->d_col_ptr, ((size_t)n + 1) * sizeof(int))) != hipSuccess ||
+        (e = hipMalloc((void**)&c->d_edge_col, eb)) != hipSuccess ||
+        (e = hipMalloc((void**)&c->d_col_edge, eb)) != hipSuccess)
+        return bail(LDPC_AMD_ENOMEM, std::string("create: hipMalloc: ") + hipGetErrorString(e));
+    if ((e = hipMemcpy(c->d_row_ptr, c->h_row_ptr.data(), ((size_t)m + 1) * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(c->d_col_ptr, c->h_col_ptr.data(), ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess ||
+        (c->E && (e = hipMemcpy(c->d_edge_col, c->h_edge_col.data(), (size_t)c->E * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) ||
+        (c->E && (e = hipMemcpy(c->d_col_edge, c->h_col_edge.data(), (size_t)c->E * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess))
+        return bail(LDPC_AMD_EHIP, std::string("create: hipMemcpy: ") + hipGetErrorString(e));
+    *out = c;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_destroy(ldpc_amd_ctx* c) {
+    if (!c) return LDPC_AMD_OK;
+    {
+        DeviceGuard guard(c->device);
+        (void)hipDeviceSynchronize();
+        for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+        void* ptrs[] = {c->d_row_ptr, c->d_edge_col, c->d_col_ptr, c->d_col_edge, c->ws,
+                        c->stage[0],  c->stage[1],   c->stage[2],  c->stage[3],   c->d_counters};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    delete c;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_info(const ldpc_amd_ctx* c, int32_t* m, int32_t* n, int64_t* edges, int32_t* max_dc, int32_t* max_dv) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (m) *m = c->m;
+    if (n) *n = c->n;
+    if (edges) *edges = c->E;
+    if (max_dc) *max_dc = c->max_dc;
+    if (max_dv) *max_dv = c->max_dv;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_graph(const ldpc_amd_ctx* c, int32_t* row_ptr, int32_t* edge_col, int32_t* col_ptr, int32_t* col_edge) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (row_ptr) memcpy(row_ptr, c->h_row_ptr.data(), c->h_row_ptr.size() * sizeof(int));
+    if (edge_col) memcpy(edge_col, c->h_edge_col.data(), c->h_edge_col.size() * sizeof(int));
+    if (col_ptr) memcpy(col_ptr, c->h_col_ptr.data(), c->h_col_ptr.size() * sizeof(int));
+    if (col_edge) memcpy(col_edge, c->h_col_edge.data(), c->h_col_edge.size() * sizeof(int));
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_set_cn_rule(ldpc_amd_ctx* c, int32_t cn_rule) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (cn_rule != LDPC_AMD_CN_SUMPRODUCT && cn_rule != LDPC_AMD_CN_MINSUM)
+        return fail(c, LDPC_AMD_EINVAL, "unknown check-node rule");
+    c->cn_rule = cn_rule;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* c, uint64_t bytes) {
+    if (!c) return LDPC_AMD_EINVAL;
+    c->ws_limit = bytes;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_decode_batch_dev(ldpc_amd_ctx* c, const float* d_llr, int64_t frames, int32_t max_iters,
+                              int32_t early_term, uint8_t* d_hard, int32_t* d_iters, int32_t* d_synd, void* stream) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (!d_llr && frames > 0) return fail(c, LDPC_AMD_EINVAL, "decode_batch: llr is null");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    SrcArgs src{Src::Float, d_llr, nullptr, 0.f, 0.f};
+    return decode_dev(c, src, frames, max_iters, early_term, d_hard, d_iters, d_synd, (hipStream_t)stream);
+}
+
+int ldpc_amd_decode_bsc_batch_dev(ldpc_amd_ctx* c, const uint8_t* d_r, int64_t frames, double e, int32_t llr_mode,
+                                  int32_t max_iters, int32_t early_term, uint8_t* d_hard, int32_t* d_iters,
+                                  int32_t* d_synd, void* stream) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (!d_r && frames > 0) return fail(c, LDPC_AMD_EINVAL, "decode_bsc_batch: r is null");
+    float l0, l1;
+    if (int rc = bsc_magnitudes(c, e, llr_mode, &l0, &l1)) return rc;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    SrcArgs src{Src::Bsc, nullptr, d_r, l0, l1};
+    return decode_dev(c, src, frames, max_iters, early_term, d_hard, d_iters, d_synd, (hipStream_t)stream);
+}
+
+// Host-pointer variants: stage a chunk of frames through device buffers.
+static int decode_host(ldpc_amd_ctx* c, const void* in, size_t in_elem, bool bsc, double e, int llr_mode,
+                       int64_t frames, int32_t max_iters, int32_t early_term, uint8_t* hard, int32_t* iters,
+                       int32_t* synd) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (frames < 0 || (frames > 0 && (!in || !hard))) return fail(c, LDPC_AMD_EINVAL, "decode: null buffer");
+    float l0 = 0.f, l1 = 0.f;
+    if (bsc)
+        if (int rc = bsc_magnitudes(c, e, llr_mode, &l0, &l1)) return rc;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    const size_t n = (size_t)c->n;
+    const long long chunk = std::max<long long>(1, std::min<long long>(frames, (long long)((512ull << 20) / (n * 4))));
+    int launches = 0;
+    long long tframes = 0;
+    for (long long f0 = 0; f0 < frames; f0 += chunk) {
+        const long long nf = std::min<long long>(chunk, frames - f0);
+        if (int rc = ensure_stage(c, 0, (size_t)nf * n * in_elem)) return rc;
+        if (int rc = ensure_stage(c, 1, (size_t)nf * n)) return rc;
+        if (int rc = ensure_stage(c, 2, (size_t)nf * 4)) return rc;
+        if (int rc = ensure_stage(c, 3, (size_t)nf * 4)) return rc;
+        LDPC_HIP(c, hipMemcpy(c->stage[0], (const char*)in + (size_t)f0 * n * in_elem, (size_t)nf * n * in_elem,
+                              hipMemcpyHostToDevice));
+        SrcArgs src{bsc ? Src::Bsc : Src::Float, (const float*)c->stage[0], (const uint8_t*)c->stage[0], l0, l1};
+        if (int rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)c->stage[1], (int32_t*)c->stage[2],
+                                (int32_t*)c->stage[3], nullptr))
+            return rc;
+        LDPC_HIP(c, hipMemcpy(hard + (size_t)f0 * n, c->stage[1], (size_t)nf * n, hipMemcpyDeviceToHost));
+        if (iters) LDPC_HIP(c, hipMemcpy(iters + f0, c->stage[2], (size_t)nf * 4, hipMemcpyDeviceToHost));
+        if (synd) LDPC_HIP(c, hipMemcpy(synd + f0, c->stage[3], (size_t)nf * 4, hipMemcpyDeviceToHost));
+        launches += c->timed_launches;
+        tframes += c->timed_frames;
+    }
+    (void)launches; (void)tframes;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_decode_batch(ldpc_amd_ctx* c, const float* llr, int64_t frames, int32_t max_iters, int32_t early_term,
+                          uint8_t* hard, int32_t* iters, int32_t* synd) {
+    return decode_host(c, llr, sizeof(float), false, 0.0, 0, frames, max_iters, early_term, hard, iters, synd);
+}
+
+int ldpc_amd_decode_bsc_batch(ldpc_amd_ctx* c, const uint8_t* r, int64_t frames, double e, int32_t llr_mode,
+                              int32_t max_iters, int32_t early_term, uint8_t* hard, int32_t* iters, int32_t* synd) {
+    return decode_host(c, r, 1, true, e, llr_mode, frames, max_iters, early_term, hard, iters, synd);
+}
+
+int ldpc_amd_gen_bsc_dev(ldpc_amd_ctx* c, int32_t channel, double e, uint64_t seed, int64_t first_frame,
+                         int64_t frames, uint8_t* d_r, void* stream) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (frames < 0 || (frames > 0 && !d_r)) return fail(c, LDPC_AMD_EINVAL, "gen_bsc: bad argument");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    return gen_bsc(c, channel, e, seed, first_frame, frames, d_r, (hipStream_t)stream);
+}
+
+int ldpc_amd_gen_awgn_llr_dev(ldpc_amd_ctx* c, double ebn0_db, uint64_t seed, int64_t first_frame, int64_t frames,
+                              float* d_llr, void* stream) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (frames < 0 || (frames > 0 && !d_llr)) return fail(c, LDPC_AMD_EINVAL, "gen_awgn: bad argument");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    return gen_awgn(c, ebn0_db, seed, first_frame, frames, d_llr, (hipStream_t)stream);
+}
+
+int ldpc_amd_count_errors_dev(ldpc_amd_ctx* c, int64_t frames, const uint8_t* d_hard, const uint8_t* d_rx_hard,
+                              const int32_t* d_iters, const int32_t* d_synd, int32_t max_iters, uint64_t* d_counters,
+                              void* stream) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (frames < 0 || max_iters < 0 || (frames > 0 && (!d_hard || !d_iters || !d_synd || !d_counters)))
+        return fail(c, LDPC_AMD_EINVAL, "count_errors: bad argument");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    return count_launch(c, frames, d_hard, d_rx_hard, nullptr, d_iters, d_synd, max_iters,
+                        (unsigned long long*)d_counters, (hipStream_t)stream);
+}
+
+int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t seed, int64_t first_frame,
+                      int64_t frames, int32_t max_iters, int32_t early_term, uint64_t* counters) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (frames < 0 || max_iters < 0 || !counters) return fail(c, LDPC_AMD_EINVAL, "simulate: bad argument");
+    if (channel != LDPC_AMD_CH_BSC_INFO && channel != LDPC_AMD_CH_BSC_ALL && channel != LDPC_AMD_CH_AWGN)
+        return fail(c, LDPC_AMD_EINVAL, "simulate: unknown channel");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    const size_t n = (size_t)c->n;
+    const size_t nc = (size_t)LDPC_AMD_CNT_FIXED + (size_t)max_iters;
+    if (c->counters_len < nc) {
+        if (c->d_counters) LDPC_HIP(c, hipFree(c->d_counters));
+        c->d_counters = nullptr;
+        LDPC_HIP(c, hipMalloc((void**)&c->d_counters, nc * sizeof(unsigned long long)));
+        c->counters_len = nc;
+    }
+    LDPC_HIP(c, hipMemset(c->d_counters, 0, nc * sizeof(unsigned long long)));
+    float l0 = 0.f, l1 = 0.f;
+    const bool awgn = channel == LDPC_AMD_CH_AWGN;
+    if (!awgn) {
+        const int mode = (channel == LDPC_AMD_CH_BSC_INFO) ? LDPC_AMD_LLR_PARITY_LN1E20 : LDPC_AMD_LLR_UNIFORM;
+        if (int rc = bsc_magnitudes(c, param, mode, &l0, &l1)) return rc;
+    }
+    const size_t in_elem = awgn ? sizeof(float) : 1;
+    long long chunk = (long long)((2048ull << 20) / (n * (in_elem + 1) + 8));
+    chunk = std::max<long long>(256, std::min<long long>(chunk, 1ll << 20));
+    chunk = std::min<long long>(chunk, std::max<long long>(frames, 1));
+    for (long long f0 = 0; f0 < frames; f0 += chunk) {
+        const long long nf = std::min<long long>(chunk, frames - f0);
+        if (int rc = ensure_stage(c, 0, (size_t)nf * n * in_elem)) return rc;
+        if (int rc = ensure_stage(c, 1, (size_t)nf * n)) return rc;
+        if (int rc = ensure_stage(c, 2, (size_t)nf * 4)) return rc;
+        if (int rc = ensure_stage(c, 3, (size_t)nf * 4)) return rc;
+        int rc;
+        SrcArgs src{};
+        if (awgn) {
+            rc = gen_awgn(c, param, seed, first_frame + f0, nf, (float*)c->stage[0], nullptr);
+            src = SrcArgs{Src::Float, (const float*)c->stage[0], nullptr, 0.f, 0.f};
+        } else {
+            rc = gen_bsc(c, channel, param, seed, first_frame + f0, nf, (uint8_t*)c->stage[0], nullptr);
+            src = SrcArgs{Src::Bsc, nullptr, (const uint8_t*)c->stage[0], l0, l1};
+        }
+        if (rc) return rc;
+        rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)c->stage[1], (int32_t*)c->stage[2],
+                        (int32_t*)c->stage[3], nullptr);
+        if (rc) return rc;
+        if (max_iters == 0) {
+            // nothing ran: the histogram has no bin for 0 iterations, the fixed counters still apply
+        }
+        rc = count_launch(c, nf, (const uint8_t*)c->stage[1], awgn ? nullptr : (const uint8_t*)c->stage[0],
+                          awgn ? (const float*)c->stage[0] : nullptr, (const int32_t*)c->stage[2],
+                          (const int32_t*)c->stage[3], max_iters, c->d_counters, nullptr);
+        if (rc) return rc;
+    }
+    std::vector<unsigned long long> h(nc);
+    LDPC_HIP(c, hipMemcpy(h.data(), c->d_counters, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nc; ++i) counters[i] += h[i];
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_last_decode_timing(ldpc_amd_ctx* c, int32_t* launches, double* kernel_ms, int64_t* frames) {
+    if (!c) return LDPC_AMD_EINVAL;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    double total = 0.0;
+    for (int i = 0; i < c->timed_launches; ++i) {
+        LDPC_HIP(c, hipEventSynchronize(c->ev[(size_t)(2 * i + 1)]));
+        float ms = 0.f;
+        LDPC_HIP(c, hipEventElapsedTime(&ms, c->ev[(size_t)(2 * i)], c->ev[(size_t)(2 * i + 1)]));
+        total += ms;
+    }
+    if (launches) *launches = c->timed_launches;
+    if (kernel_ms) *kernel_ms = total;
+    if (frames) *frames = c->timed_frames;
+    return LDPC_AMD_OK;
+}
+
+}  // extern "C"

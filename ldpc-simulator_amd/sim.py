@@ -1,0 +1,68 @@
+"""Monte-Carlo frames sharded over the GPUs of one node.
+
+Frames are independent (the reference runs them as an unordered parallel stream,
+LDPC_GallagerIntStreamSimu.java:99), so rank r of W takes a contiguous range of global
+frame indices and no data moves between ranks while decoding.  The only exchange is the
+sum of the counter vectors, which replaces the reference's synchronized(lock) block
+(LDPC_GallagerIntStreamSimu.java:139-183): one all-reduce of (16 + maxL) integers.
+The channel generator is keyed by the global frame index, so the union of what W ranks
+decode is the same set of frames for every W.
+"""
+import numpy as np
+
+from . import capi
+
+
+def shard_range(first_frame, frames, rank, world):
+    """Contiguous share of [first_frame, first_frame + frames) for `rank` of `world`."""
+    base, extra = divmod(int(frames), int(world))
+    start = first_frame + rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+def allreduce_counters(counters, device=None):
+    """Sum a uint64 counter vector over the default process group (RCCL on GPUs, gloo on
+    CPU).  With no initialised process group the vector is returned unchanged."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return counters
+    t = torch.from_numpy(counters.astype(np.int64))
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy().astype(np.uint64)
+
+
+def simulate_sharded(simulate_fn, first_frame, frames, max_iters, rank=0, world=1, device=None):
+    """Run `simulate_fn(first, count) -> uint64[16 + max_iters]` on this rank's share and
+    return the all-reduced counters.  On a GPU `simulate_fn` is Decoder.simulate bound to
+    a channel; tests inject a CPU stand-in to exercise the sharding and the reduction."""
+    start, count = shard_range(first_frame, frames, rank, world)
+    local = np.zeros(capi.CNT_FIXED + int(max_iters), np.uint64)
+    if count > 0:
+        local = np.asarray(simulate_fn(start, count), dtype=np.uint64)
+    return allreduce_counters(local, device)
+
+
+def rates(counters, m, n):
+    """FER / IFER / CFER / IBER / mean iterations as LDPC_GallagerIntStreamSimu.java:186-212
+    derives them from the counters."""
+    c = np.asarray(counters, dtype=np.float64)
+    frames = c[capi.CNT_FRAMES]
+    k = n - m
+    nan = float("nan")
+    ok = frames - c[capi.CNT_FRAME_ERRORS]
+    return {
+        "frames": int(frames),
+        "FER": c[capi.CNT_FRAME_ERRORS] / frames if frames else nan,
+        "IFER": c[capi.CNT_INFO_FRAME_ERRORS] / frames if frames else nan,
+        "CFER": c[capi.CNT_CHECK_FRAME_ERRORS] / frames if frames else nan,
+        "IBER": c[capi.CNT_INFO_BIT_ERRORS] / (k * frames) if frames and k else nan,
+        "undetected": int(c[capi.CNT_UNDETECTED]),
+        "miscorrected_bits": int(c[capi.CNT_MISCORRECTED]),
+        "avg_iters_correct": c[capi.CNT_ITERS_CORRECT] / ok if ok else nan,
+        "avg_iters_wrong": c[capi.CNT_ITERS_WRONG] / c[capi.CNT_FRAME_ERRORS] if c[capi.CNT_FRAME_ERRORS] else nan,
+        "channel_BER": c[capi.CNT_CHANNEL_ERRORS] / (k * frames) if frames and k else nan,
+    }

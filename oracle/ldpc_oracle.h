@@ -1,0 +1,105 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU oracle for the sum-product decoder path.
+ *
+ * Double-precision restatement of the reference's flooding belief-propagation
+ * decoder (src/LDPC/LogDecoder.java, src/LDPC/LogDecoderBefore.java,
+ * src/LDPC/MinSumDecoder.java), its channel (src/LDPC/Channel.java) and its
+ * per-frame error accounting (src/LDPC/LDPC_GallagerIntStreamSimu.java:136-183).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library; the product path never does.
+ *
+ * PARITY UNPINNED by the reference: it ships no tests, no golden vectors and no
+ * seeded run, and no JVM exists in the build container to execute it.  The pins
+ * are (1) closed-form known answers, (2) a second, independent NumPy
+ * restatement (oracle/np_restatement.py) that must agree with this file, and
+ * (3) the dense, line-by-line mode below agreeing with the sparse mode.
+ */
+#ifndef LDPC_ORACLE_H
+#define LDPC_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_graph oracle_graph;
+
+/* check-node rules */
+enum { ORACLE_CN_SUMPRODUCT = 0, ORACLE_CN_MINSUM = 1 };
+/* BSC LLR modes (LogDecoder.java:45-54 / LogDecoderBefore.java:45-50 / MinSumDecoder.java:40-48) */
+enum { ORACLE_LLR_UNIFORM = 0, ORACLE_LLR_PARITY_LN1E20 = 1, ORACLE_LLR_PARITY_1EM7 = 2 };
+/* channels (Channel.java:5-17, :28-39; AWGN is not in the reference) */
+enum { ORACLE_CH_BSC_INFO = 0, ORACLE_CH_BSC_ALL = 1, ORACLE_CH_AWGN = 2 };
+
+#define ORACLE_NUM_FIXED_COUNTERS 16
+
+/* COO (row, col) pairs in any order; duplicates and out-of-range pairs are
+ * dropped as CheckMatrixIO.loadCheckMatrix does (CheckMatrixIO.java:37-45). */
+int  oracle_graph_create(int m, int n, int64_t nnz, const int32_t* rows, const int32_t* cols,
+                         oracle_graph** out);
+void oracle_graph_destroy(oracle_graph* g);
+int64_t oracle_graph_edges(const oracle_graph* g);
+/* copies of the adjacency, for indexing tests */
+void oracle_graph_csr(const oracle_graph* g, int32_t* row_ptr, int32_t* edge_col);
+void oracle_graph_csc(const oracle_graph* g, int32_t* col_ptr, int32_t* col_edge);
+
+/* One frame, channel LLRs in (double), sparse state, reference arithmetic order.
+ * early_term=1 is the reference's behaviour (LogDecoder.java:117-119).
+ * alpha_out/beta_out (length E, CSR edge order) may be NULL. */
+int oracle_decode_llr(const oracle_graph* g, const double* llr, int max_iters, int early_term,
+                      int cn_rule, uint8_t* hard, int32_t* iters, int32_t* syndrome_weight,
+                      double* alpha_out, double* beta_out);
+
+/* Frame batch from float LLRs (what the GPU path is fed), frame-parallel over
+ * `threads` OpenMP threads.  llr is [frames][n]; hard is [frames][n]. */
+int oracle_decode_llr_batch_f32(const oracle_graph* g, const float* llr, int64_t frames,
+                                int max_iters, int early_term, int cn_rule, uint8_t* hard,
+                                int32_t* iters, int32_t* syndrome_weight, int threads);
+
+/* lambda from a hard received word, LogDecoder.java:45-54 and variants. */
+void oracle_bsc_llr(int m, int n, const uint8_t* r, double e, int llr_mode, double* llr);
+
+/* Line-by-line dense mode: dense m x n message arrays allocated per call, adjacency
+ * rebuilt from the dense H per call, d*(d-1) tanh per check, dense syndrome
+ * (LogDecoder.java:17-123).  H is row-major int32 [m][n]; r, decoded are int32 [n]. */
+int oracle_logdecoder_dense(const int32_t* H, int m, int n, const int32_t* r, double e,
+                            int max_iters, int llr_mode, int cn_rule, int32_t* decoded,
+                            int32_t* iters, int32_t* syndrome);
+
+/* Batch of the dense mode over frames of hard words (the Java path's cost model). */
+int oracle_logdecoder_dense_batch(const int32_t* H, int m, int n, const uint8_t* r, int64_t frames,
+                                  double e, int max_iters, int llr_mode, uint8_t* hard,
+                                  int32_t* iters, int32_t* syndrome, int threads);
+
+/* Philox4x32-10 (Salmon et al., SC'11), the counter-based generator the device path uses. */
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* Received hard words for the all-zero codeword, frames first_frame..first_frame+frames-1.
+ * channel = ORACLE_CH_BSC_INFO flips only j < n-m (Channel.java:8-15), ORACLE_CH_BSC_ALL
+ * flips every position (Channel.java:31-37).  r is [frames][n]. */
+void oracle_gen_bsc(int m, int n, int channel, double e, uint64_t seed, int64_t first_frame,
+                    int64_t frames, uint8_t* r);
+/* BPSK/AWGN channel LLRs of the all-zero codeword at Eb/N0 (dB), rate (n-m)/n. llr [frames][n]. */
+void oracle_gen_awgn_llr(int m, int n, double ebn0_db, uint64_t seed, int64_t first_frame,
+                         int64_t frames, float* llr);
+
+/* Error accounting against the all-zero codeword
+ * (LDPC_GallagerIntStreamSimu.java:136-183).  counters has 16 + max_iters entries and is
+ * ACCUMULATED into.  rx_hard is the channel's hard decision per position. */
+void oracle_count_errors(int m, int n, int64_t frames, const uint8_t* hard, const uint8_t* rx_hard,
+                         const int32_t* iters, const int32_t* syndrome_weight, int max_iters,
+                         uint64_t* counters);
+
+/* Whole Monte-Carlo leg on the CPU: generate, decode, count. */
+int oracle_simulate(const oracle_graph* g, int channel, double param, uint64_t seed,
+                    int64_t first_frame, int64_t frames, int max_iters, int early_term,
+                    int cn_rule, uint64_t* counters, int threads);
+
+int oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,283 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bars: graph indexing, syndrome weight, channel bits and counters are integer work and must
+be bit-exact.  Hard decisions come from fp32 messages on the GPU and double messages in
+the oracle: the bar is agreement on >= 99.99 % of frames where the sample is large enough to
+resolve that, and the disagreeing frames are itemised in the assertion message.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense(m, n, rows, cols):
+    H = np.zeros((m, n), np.int32)
+    H[rows, cols] = 1
+    return H
+
+
+def _syndrome_weight(H, hard):
+    return ((hard.astype(np.int64) @ H.T.astype(np.int64)) % 2).sum(axis=1)
+
+
+def _agreement(a, b):
+    """fraction of frames whose (hard, iters, synd) triples are identical"""
+    same = (a[0] == b[0]).all(axis=1) & (a[1] == b[1]) & (a[2] == b[2])
+    return same.mean(), np.nonzero(~same)[0]
+
+
+@pytest.fixture(scope="module")
+def c1(pkg, oracle):
+    m, n, rows, cols = pkg.codes.gallager(1024, 8, 2, seed=1)
+    return dict(m=m, n=n, rows=rows, cols=cols, dec=pkg.Decoder(m, n, rows, cols), g=oracle.Graph(m, n, rows, cols))
+
+
+@pytest.fixture(scope="module")
+def c2(pkg, oracle):
+    m, n, rows, cols = pkg.codes.regular_ldpc(4096, 3, 6, seed=1)
+    return dict(m=m, n=n, rows=rows, cols=cols, dec=pkg.Decoder(m, n, rows, cols), g=oracle.Graph(m, n, rows, cols))
+
+
+def test_graph_indexing_bit_exact(c1, c2):
+    for c in (c1, c2):
+        rp, ec, cp, ce = c["dec"].graph()
+        orp, oec = c["g"].csr()
+        ocp, oce = c["g"].csc()
+        assert (rp == orp).all() and (ec == oec).all() and (cp == ocp).all() and (ce == oce).all()
+
+
+def test_closed_form_and_special_values(pkg):
+    # H = [1 1 1]: decision 000 after one iteration (see tests/test_oracle_known_answers.py)
+    res = pkg.LogDecoder.decode([[1, 1, 1]], [0, 0, 0], 0.1, 5)
+    assert res.decodedCode.tolist() == [0, 0, 0] and res.iterationNum == 1 and res.syndrome == 0
+    # +Inf and -Inf meet in v0 -> NaN posterior -> bit 0 (LogDecoder.java:104)
+    H = [[1, 1, 0], [1, 0, 1]]
+    res = pkg.LogDecoder.decode(H, [1, 0, 1], 0.1, 3)
+    from oracle import oracle_capi as oc
+    dec, it, sy = oc.logdecoder_dense(np.array(H, np.int32), [1, 0, 1], 0.1, 3)
+    assert res.decodedCode.tolist() == dec.tolist() and res.iterationNum == it and res.syndrome == sy
+    assert res.decodedCode[0] == 0
+    # degree-1 check: alpha = +Inf forces bit 0
+    d = pkg.Decoder(1, 2, [0], [0])
+    hard, it, sw = d.decode_batch(np.array([[-5.0, 3.0]], np.float32), 2, True)
+    assert hard.tolist() == [[0, 0]] and it[0] == 1 and sw[0] == 0
+    # maxL = 0 -> all-zero word, 0 iterations, syndrome 0
+    hard, it, sw = d.decode_batch(np.array([[-5.0, -3.0]], np.float32), 0, True)
+    assert hard.tolist() == [[0, 0]] and it[0] == 0 and sw[0] == 0
+    # empty batch
+    hard, it, sw = d.decode_batch(np.zeros((0, 2), np.float32), 5, True)
+    assert hard.shape == (0, 2)
+
+
+@pytest.mark.parametrize("mode", ["LogDecoder", "LogDecoderBefore"])
+def test_c1_bsc_reference_grid(c1, oracle, pkg, mode):
+    """The reference's own configuration: n=1024, wr=8, wc=2, maxL=50 and its e grid
+    (LDPC_GallagerIntStreamSimu.java:20-30)."""
+    m, n = c1["m"], c1["n"]
+    llr_mode = oracle.LLR_PARITY_LN1E20 if mode == "LogDecoder" else oracle.LLR_UNIFORM
+    ch = oracle.CH_BSC_INFO if mode == "LogDecoder" else oracle.CH_BSC_ALL
+    tot = bad = 0
+    notes = []
+    for e in (0.001, 0.005, 0.01, 0.02, 0.03, 0.05):
+        F = 1500
+        r = oracle.gen_bsc(m, n, ch, e, seed=11, first_frame=0, frames=F)
+        got = c1["dec"].decode_bsc_batch(r, e, 50, llr_mode, True)
+        lam = np.stack([oracle.bsc_llr(m, n, r[f], e, llr_mode) for f in range(F)]).astype(np.float32)
+        want = c1["g"].decode_llr_batch(lam, 50, True)
+        frac, diff = _agreement(got, want)
+        tot += F
+        bad += diff.size
+        if diff.size:
+            notes.append((e, diff[:5].tolist(), got[1][diff[:5]].tolist(), want[1][diff[:5]].tolist()))
+        # syndrome weight is bit-exact for the GPU's own word
+        H = _dense(m, n, c1["rows"], c1["cols"])
+        assert (_syndrome_weight(H, got[0]) == got[2]).all()
+    assert bad / tot <= 1e-3, "disagreeing frames: %s" % notes
+    print("%s: %d of %d frames differ from the double oracle %s" % (mode, bad, tot, notes))
+
+
+def test_c2_awgn_early_exit(c2, oracle):
+    m, n = c2["m"], c2["n"]
+    F = 3000
+    llr = oracle.gen_awgn_llr(m, n, 2.0, seed=3, first_frame=0, frames=F)
+    got = c2["dec"].decode_batch(llr, 50, True)
+    want = c2["g"].decode_llr_batch(llr, 50, True)
+    frac, diff = _agreement(got, want)
+    assert frac >= 0.999, (frac, diff[:10], got[1][diff[:10]], want[1][diff[:10]])
+    H = _dense(m, n, c2["rows"], c2["cols"])
+    assert (_syndrome_weight(H, got[0]) == got[2]).all()
+    print("C2 2.0 dB early-exit: %d of %d frames differ" % (diff.size, F))
+
+
+def test_c2_fixed_iterations_four_frames_per_lane(c2, oracle):
+    """early_term = 0 runs the 4-frames-per-lane kernel; ragged frame count (not a multiple
+    of 256) exercises the tile tail."""
+    m, n = c2["m"], c2["n"]
+    F = 700
+    llr = oracle.gen_awgn_llr(m, n, 2.5, seed=5, first_frame=0, frames=F)
+    got = c2["dec"].decode_batch(llr, 10, False)
+    want = c2["g"].decode_llr_batch(llr, 10, False)
+    assert (got[1] == 10).all()
+    frac, diff = _agreement(got, want)
+    assert frac >= 0.995, (frac, diff[:10])
+    H = _dense(m, n, c2["rows"], c2["cols"])
+    assert (_syndrome_weight(H, got[0]) == got[2]).all()
+
+
+def test_batch_split_and_rerun_invariance(c2, oracle):
+    m, n = c2["m"], c2["n"]
+    llr = oracle.gen_awgn_llr(m, n, 1.5, seed=8, first_frame=0, frames=600)
+    a = c2["dec"].decode_batch(llr, 20, True)
+    b = c2["dec"].decode_batch(llr, 20, True)
+    for x, y in zip(a, b):
+        assert (x == y).all()
+    p1 = c2["dec"].decode_batch(llr[:131], 20, True)
+    p2 = c2["dec"].decode_batch(llr[131:], 20, True)
+    for x, y1, y2 in zip(a, p1, p2):
+        assert (x == np.concatenate([y1, y2])).all()
+    # fixed-iteration kernel (4 frames per lane) against the early-exit kernel run to the same depth
+    f1 = c2["dec"].decode_batch(llr, 7, False)
+    c2["dec"].set_workspace_limit(64 << 20)  # forces several rounds
+    f2 = c2["dec"].decode_batch(llr, 7, False)
+    c2["dec"].set_workspace_limit(0)
+    for x, y in zip(f1, f2):
+        assert (x == y).all()
+
+
+def test_irregular_degrees_register_and_lds_paths(pkg, oracle):
+    """NR-BG1-shaped code at a small lifting size: check degrees 3..19 and variable degrees
+    1..30 go through the register path (<= 16) and the LDS-staged path (> 16)."""
+    base, (m, n, rows, cols) = pkg.codes.nr_bg1_shaped(z=8, seed=1)
+    dec = pkg.Decoder(m, n, rows, cols)
+    assert dec.max_dc == 19 and dec.max_dv >= 29
+    g = oracle.Graph(m, n, rows, cols)
+    F = 2000
+    llr = oracle.gen_awgn_llr(m, n, 3.0, seed=2, first_frame=0, frames=F)
+    for early in (True, False):
+        got = dec.decode_batch(llr, 15, early)
+        want = g.decode_llr_batch(llr, 15, early)
+        frac, diff = _agreement(got, want)
+        assert frac >= 0.995, (early, frac, diff[:10])
+        H = _dense(m, n, rows, cols)
+        assert (_syndrome_weight(H, got[0]) == got[2]).all()
+
+
+def test_odd_shapes(pkg, oracle):
+    """n not a multiple of 4, 32 or 64; a degree-0 variable and a degree-0 check."""
+    rng = np.random.default_rng(0)
+    m, n = 37, 101
+    H = (rng.random((m, n)) < 0.06).astype(np.int32)
+    H[:, 17] = 0
+    H[5, :] = 0
+    rows, cols = np.nonzero(H)
+    dec = pkg.Decoder(m, n, rows, cols)
+    g = oracle.Graph(m, n, rows, cols)
+    llr = rng.normal(1.5, 2.0, size=(333, n)).astype(np.float32)
+    for early in (True, False):
+        got = dec.decode_batch(llr, 6, early)
+        want = g.decode_llr_batch(llr, 6, early)
+        frac, diff = _agreement(got, want)
+        assert frac >= 0.99, (early, frac, diff[:10])
+        assert (_syndrome_weight(H, got[0]) == got[2]).all()
+
+
+def test_minsum(c1, oracle, pkg):
+    m, n = c1["m"], c1["n"]
+    dec = pkg.Decoder(m, n, c1["rows"], c1["cols"])
+    dec.set_cn_rule(pkg.capi.CN_MINSUM)
+    F = 1000
+    e = 0.03
+    r = oracle.gen_bsc(m, n, oracle.CH_BSC_INFO, e, seed=21, first_frame=0, frames=F)
+    got = dec.decode_bsc_batch(r, e, 50, oracle.LLR_PARITY_1EM7, True)
+    lam = np.stack([oracle.bsc_llr(m, n, r[f], e, oracle.LLR_PARITY_1EM7) for f in range(F)]).astype(np.float32)
+    want = c1["g"].decode_llr_batch(lam, 50, True, cn_rule=oracle.CN_MINSUM)
+    frac, diff = _agreement(got, want)
+    assert frac >= 0.995, (frac, diff[:10])
+
+
+def test_device_channel_bit_exact_and_llr_close(c1, oracle):
+    import torch
+    m, n, dec = c1["m"], c1["n"], c1["dec"]
+    F = 300
+    for ch in (oracle.CH_BSC_INFO, oracle.CH_BSC_ALL):
+        d_r = torch.empty((F, n), dtype=torch.uint8, device="cuda")
+        dec.gen_bsc_dev(ch, 0.04, 77, 1000, F, d_r.data_ptr())
+        torch.cuda.synchronize()
+        assert (d_r.cpu().numpy() == oracle.gen_bsc(m, n, ch, 0.04, 77, 1000, F)).all()
+    d_llr = torch.empty((F, n), dtype=torch.float32, device="cuda")
+    dec.gen_awgn_llr_dev(1.0, 5, 123456789012, F, d_llr.data_ptr())
+    torch.cuda.synchronize()
+    want = oracle.gen_awgn_llr(m, n, 1.0, 5, 123456789012, F)
+    got = d_llr.cpu().numpy()
+    # same Philox words; logf/sinf/cosf differ by ulps between the device library and glibc
+    assert np.allclose(got, want, rtol=2e-5, atol=2e-5)
+
+
+def test_simulate_counters_match_oracle(c1, oracle, pkg):
+    dec, g = c1["dec"], c1["g"]
+    for ch, param in ((oracle.CH_BSC_INFO, 0.03), (oracle.CH_BSC_ALL, 0.02)):
+        got = dec.simulate(ch, param, seed=9, first_frame=500, frames=2000, max_iters=50)
+        want = g.simulate(ch, param, seed=9, first_frame=500, frames=2000, max_iters=50)
+        assert got[0] == want[0] == 2000
+        assert got[10] == want[10] and got[11] == want[11]          # channel errors: integer work
+        assert abs(int(got[1]) - int(want[1])) <= 2, (got[:12], want[:12])
+        assert abs(int(got[8]) - int(want[8])) <= 60, (got[:12], want[:12])
+    # counters add over disjoint frame ranges
+    a = dec.simulate(oracle.CH_BSC_INFO, 0.03, 9, 500, 1200, 50)
+    b = dec.simulate(oracle.CH_BSC_INFO, 0.03, 9, 1700, 800, 50)
+    whole = dec.simulate(oracle.CH_BSC_INFO, 0.03, 9, 500, 2000, 50)
+    assert ((a + b) == whole).all()
+
+
+def test_dev_entry_points_and_count_errors(c2, oracle):
+    import torch
+    m, n, dec = c2["m"], c2["n"], c2["dec"]
+    F, L = 512, 12
+    llr = oracle.gen_awgn_llr(m, n, 1.2, seed=4, first_frame=0, frames=F)
+    d_llr = torch.from_numpy(llr).cuda()
+    d_hard = torch.empty((F, n), dtype=torch.uint8, device="cuda")
+    d_it = torch.empty(F, dtype=torch.int32, device="cuda")
+    d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    dec.decode_batch_dev(d_llr.data_ptr(), F, L, True, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr(), s)
+    torch.cuda.synchronize()
+    host = dec.decode_batch(llr, L, True)
+    assert (d_hard.cpu().numpy() == host[0]).all() and (d_it.cpu().numpy() == host[1]).all()
+    launches, ms, frames = dec.last_decode_timing()
+    assert launches >= 1 and ms > 0 and frames == F
+    d_cnt = torch.zeros(16 + L, dtype=torch.int64, device="cuda")
+    d_rx = (d_llr < 0).to(torch.uint8)
+    dec.count_errors_dev(F, d_hard.data_ptr(), d_rx.data_ptr(), d_it.data_ptr(), d_sw.data_ptr(), L, d_cnt.data_ptr(), s)
+    torch.cuda.synchronize()
+    want = oracle.count_errors(m, n, host[0], (llr < 0).astype(np.uint8), host[1], host[2], L)
+    assert (d_cnt.cpu().numpy().astype(np.uint64) == want).all()
+
+
+def test_full_size_properties_c2(c2, oracle):
+    """BASELINE size per frame (n=4096, 50 iterations, 4 frames per lane) on a batch too big
+    for the oracle: size-independent properties only."""
+    import torch
+    m, n, dec = c2["m"], c2["n"], c2["dec"]
+    F = 16384
+    d_llr = torch.empty((F, n), dtype=torch.float32, device="cuda")
+    dec.gen_awgn_llr_dev(3.0, 1, 0, F, d_llr.data_ptr())
+    d_hard = torch.empty((F, n), dtype=torch.uint8, device="cuda")
+    d_it = torch.empty(F, dtype=torch.int32, device="cuda")
+    d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
+    dec.decode_batch_dev(d_llr.data_ptr(), F, 50, False, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
+    torch.cuda.synchronize()
+    hard = d_hard.cpu().numpy()
+    sw = d_sw.cpu().numpy()
+    # at 3 dB every frame of this code converges to the transmitted all-zero word
+    assert (d_it.cpu().numpy() == 50).all()
+    assert hard.sum() == 0 and (sw == 0).all()
+    # noisier point: the reported weight is the weight of the reported word, frame by frame
+    dec.gen_awgn_llr_dev(0.8, 2, 0, F, d_llr.data_ptr())
+    dec.decode_batch_dev(d_llr.data_ptr(), F, 50, False, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
+    torch.cuda.synchronize()
+    H = torch.zeros((m, n), dtype=torch.float32, device="cuda")
+    H[torch.from_numpy(c2["rows"]).long().cuda(), torch.from_numpy(c2["cols"]).long().cuda()] = 1
+    w = (d_hard.float() @ H.T).remainder(2).sum(dim=1).int()
+    assert (w == d_sw).all()
+    assert (d_sw > 0).any() and (d_sw == 0).any()
