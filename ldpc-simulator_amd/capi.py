@@ -4,7 +4,9 @@ There is no CPU fallback: if the HIP library is missing or no GPU is visible, lo
 creating a decoder raises.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -13,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libldpc_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ldpc_amd.h")
 
 OK, EINVAL, ENOMEM, EHIP, ENODEV, ELIMIT = 0, -1, -2, -3, -4, -5
-CN_SUMPRODUCT, CN_MINSUM = 0, 1
+CN_SUMPRODUCT, CN_MINSUM, CN_SUMPRODUCT_TANH = 0, 1, 2
 LLR_UNIFORM, LLR_PARITY_LN1E20, LLR_PARITY_1EM7 = 0, 1, 2
 CH_BSC_INFO, CH_BSC_ALL, CH_AWGN = 0, 1, 2
 CNT_FRAMES, CNT_FRAME_ERRORS, CNT_INFO_BIT_ERRORS, CNT_CHECK_BIT_ERRORS = 0, 1, 2, 3
@@ -46,6 +48,28 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """Keep one HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so with
+    the same SONAME as ROCm's; whichever copy is loaded first serves every later library that
+    names that SONAME, but `import torch` after ROCm's copy would load the bundled file as a
+    second runtime and then fail to see the GPU.  So when PyTorch is installed its copy is
+    loaded first (without importing torch); otherwise libldpc_amd.so pulls in ROCm's."""
+    if "torch" in sys.modules or os.environ.get("LDPC_AMD_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for loc in (spec.submodule_search_locations if spec and spec.submodule_search_locations else []):
+        path = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load_library():
     """dlopen libldpc_amd.so and declare every entry point; raises if it is missing."""
     global _lib
@@ -55,6 +79,7 @@ def load_library():
         raise RuntimeError(
             "%s not found: build it with `make -C ldpc-simulator_amd/csrc` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -26,6 +26,7 @@ namespace ldpc {
 constexpr int kWave = 64;
 constexpr int kCnSumProduct = 0;
 constexpr int kCnMinSum = 1;
+constexpr int kCnLogTanh = 2;
 #ifndef LDPC_REG_DEG_FPL1
 #define LDPC_REG_DEG_FPL1 16
 #endif
@@ -126,6 +127,29 @@ __device__ __forceinline__ float atanh2(float p) {
 // Math.signum: +-0 and NaN map to themselves (MinSumDecoder.java:84)
 __device__ __forceinline__ float signum(float x) { return (x > 0.0f) ? 1.0f : (x < 0.0f) ? -1.0f : x; }
 
+// phi(x) = -ln tanh(x/2) = 2 atanh(e^-x) for x >= 0, its own inverse.  The sum-product rule
+// 2 atanh(prod tanh(beta_k/2)) equals  sign * phi(sum phi(|beta_k|)), and in this form fp32 keeps
+// ~1e-6 relative accuracy over the whole range where the double-precision reference is
+// finite: 1 - tanh never has to be formed from a value rounded next to 1.
+//   x -> 0:  1 - e^-x from its Taylor polynomial (no cancellation), phi -> +Inf at 0;
+//   x large: w = e^-x small, 2 atanh(w) from its series (ln(1 + 2w) would cancel).
+// phi(+Inf) = 0, phi(NaN) = NaN.
+__device__ __forceinline__ float phi(float x) {
+    const float w = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+    const float omw_poly =
+        x * fmaf(x, fmaf(x, fmaf(x, fmaf(x, fmaf(x, -1.0f / 720.0f, 1.0f / 120.0f), -1.0f / 24.0f), 1.0f / 6.0f), -0.5f), 1.0f);
+    const float omw = (x < 0.25f) ? omw_poly : (1.0f - w);
+    const float big = __builtin_amdgcn_logf((1.0f + w) * __builtin_amdgcn_rcpf(omw)) * 0.6931471805599453f;
+    const float w2 = w * w;
+    const float ser =
+        2.0f * w * fmaf(w2, fmaf(w2, fmaf(w2, fmaf(w2, 1.0f / 9.0f, 1.0f / 7.0f), 1.0f / 5.0f), 1.0f / 3.0f), 1.0f);
+    return (w < 0.15f) ? ser : big;
+}
+
+// |beta| above this has tanh(beta/2) == 1.0 in double (1 - tanh < 2^-54): the reference's
+// factor is exactly 1 there, so its log-domain term is exactly 0.
+constexpr float kDoubleTanhSaturation = 38.1230949f;  // 55 ln 2
+
 // beta[0..D) -> alpha[0..D) in place, D a compile-time degree.
 template <int FPL, int D, int RULE>
 __device__ __forceinline__ void cn_compute(float (&b)[D][FPL]) {
@@ -151,6 +175,37 @@ __device__ __forceinline__ void cn_compute(float (&b)[D][FPL]) {
                 const float p = pre[k][f] * suf[f];
                 suf[f] *= b[k][f];
                 b[k][f] = atanh2(p);
+            }
+    } else if constexpr (RULE == kCnLogTanh) {
+        // same rule as above in the (sign, phi) domain; sums ascend like the products they stand for
+        float pre[D][FPL];
+        uint32_t psg[D][FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) { pre[0][f] = 0.0f; psg[0][f] = 0u; }
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) {
+                const float a = fabsf(b[k][f]);
+                const uint32_t sg = __float_as_uint(b[k][f]) & 0x80000000u;
+                const float ph = (a > kDoubleTanhSaturation) ? 0.0f : phi(a);
+                b[k][f] = __uint_as_float(__float_as_uint(ph) | sg);  // phi >= 0: the sign bit carries sign(beta)
+                if (k + 1 < D) { pre[k + 1][f] = pre[k][f] + ph; psg[k + 1][f] = psg[k][f] ^ sg; }
+            }
+        float suf[FPL];
+        uint32_t ssg[FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) { suf[f] = 0.0f; ssg[f] = 0u; }
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k)
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) {
+                const float ph = fabsf(b[k][f]);
+                const uint32_t sg = __float_as_uint(b[k][f]) & 0x80000000u;
+                const float mag = phi(pre[k][f] + suf[f]);
+                b[k][f] = __uint_as_float(__float_as_uint(mag) ^ psg[k][f] ^ ssg[f]);
+                suf[f] += ph;
+                ssg[f] ^= sg;
             }
     } else {
         // MinSumDecoder.java:79-93: alpha = prod signum(beta) * min|beta| * 0.7 over k != j;
@@ -225,6 +280,29 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
             const float p = sp[k * 64] * suf;
             suf *= st[k * 64];
             row[(long long)k * T] = atanh2(p);
+        }
+    } else if constexpr (RULE == kCnLogTanh) {
+        // staged: phi_k with sign(beta_k) in its sign bit; exclusive prefix sum with the prefix sign
+        float pre = 0.0f;
+        uint32_t psg = 0u;
+        for (int k = 0; k < d; ++k) {
+            float b = FIRST ? (lam[(long long)cols[k] * T] + 0.0f) : row[(long long)k * T];
+            const float a = fabsf(b);
+            const uint32_t sg = __float_as_uint(b) & 0x80000000u;
+            const float ph = (a > kDoubleTanhSaturation) ? 0.0f : phi(a);
+            st[k * 64] = __uint_as_float(__float_as_uint(ph) | sg);
+            sp[k * 64] = __uint_as_float(__float_as_uint(pre) | psg);
+            pre += ph;
+            psg ^= sg;
+        }
+        float suf = 0.0f;
+        uint32_t ssg = 0u;
+        for (int k = d - 1; k >= 0; --k) {
+            const float sv = st[k * 64], pv = sp[k * 64];
+            const float mag = phi(fabsf(pv) + suf);
+            row[(long long)k * T] = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(pv) & 0x80000000u) ^ ssg);
+            suf += fabsf(sv);
+            ssg ^= __float_as_uint(sv) & 0x80000000u;
         }
     } else {
         // beta and the exclusive prefix minimum are staged; the exclusive prefix sign product

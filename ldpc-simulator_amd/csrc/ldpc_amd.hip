@@ -142,19 +142,20 @@ struct SrcArgs {
 template <int FPL>
 int launch_bp(ldpc_amd_ctx* c, const BpParams& p, bool early, int wpb, size_t lds_bytes, hipStream_t s) {
     const dim3 grid((unsigned)((p.tiles + wpb - 1) / wpb)), block((unsigned)(64 * wpb));
-    const bool ms = c->cn_rule == LDPC_AMD_CN_MINSUM;
-    if constexpr (FPL == 1) {
-        if (early) {
-            if (ms) hipLaunchKernelGGL((bp_decode_kernel<1, kCnMinSum, true>), grid, block, lds_bytes, s, p);
-            else    hipLaunchKernelGGL((bp_decode_kernel<1, kCnSumProduct, true>), grid, block, lds_bytes, s, p);
-        } else {
-            if (ms) hipLaunchKernelGGL((bp_decode_kernel<1, kCnMinSum, false>), grid, block, lds_bytes, s, p);
-            else    hipLaunchKernelGGL((bp_decode_kernel<1, kCnSumProduct, false>), grid, block, lds_bytes, s, p);
-        }
-    } else {
-        if (ms) hipLaunchKernelGGL((bp_decode_kernel<FPL, kCnMinSum, false>), grid, block, lds_bytes, s, p);
-        else    hipLaunchKernelGGL((bp_decode_kernel<FPL, kCnSumProduct, false>), grid, block, lds_bytes, s, p);
+#define LDPC_LAUNCH(F, R, EARLY) hipLaunchKernelGGL((bp_decode_kernel<F, R, EARLY>), grid, block, lds_bytes, s, p)
+#define LDPC_BY_RULE(F, EARLY)                                            \
+    switch (c->cn_rule) {                                                 \
+        case LDPC_AMD_CN_MINSUM: LDPC_LAUNCH(F, kCnMinSum, EARLY); break; \
+        case LDPC_AMD_CN_SUMPRODUCT_TANH: LDPC_LAUNCH(F, kCnSumProduct, EARLY); break; \
+        default: LDPC_LAUNCH(F, kCnLogTanh, EARLY); break;                \
     }
+    if constexpr (FPL == 1) {
+        if (early) { LDPC_BY_RULE(1, true) } else { LDPC_BY_RULE(1, false) }
+    } else {
+        LDPC_BY_RULE(FPL, false)
+    }
+#undef LDPC_BY_RULE
+#undef LDPC_LAUNCH
     LDPC_HIP(c, hipGetLastError());
     return LDPC_AMD_OK;
 }
@@ -427,7 +428,7 @@ int ldpc_amd_graph(const ldpc_amd_ctx* c, int32_t* row_ptr, int32_t* edge_col, i
 
 int ldpc_amd_set_cn_rule(ldpc_amd_ctx* c, int32_t cn_rule) {
     if (!c) return LDPC_AMD_EINVAL;
-    if (cn_rule != LDPC_AMD_CN_SUMPRODUCT && cn_rule != LDPC_AMD_CN_MINSUM)
+    if (cn_rule != LDPC_AMD_CN_SUMPRODUCT && cn_rule != LDPC_AMD_CN_MINSUM && cn_rule != LDPC_AMD_CN_SUMPRODUCT_TANH)
         return fail(c, LDPC_AMD_EINVAL, "unknown check-node rule");
     c->cn_rule = cn_rule;
     return LDPC_AMD_OK;

@@ -1,0 +1,159 @@
+"""CPU-side checks: the C ABI library loads and exports every symbol the header declares,
+compute entry points fail loudly without a GPU, the H text format and the code builders
+behave as the reference's, and the N > 1 path (frame sharding + counter all-reduce) works
+with world_size 2 on gloo."""
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "ldpc_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ldpc_amd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.capi.load_library()
+    names = _declared_functions()
+    assert len(names) >= 17
+    for name in names:
+        assert hasattr(lib, name), "libldpc_amd.so does not export %s" % name
+    assert sorted(pkg.capi.SIGNATURES) == names, "capi.SIGNATURES and include/ldpc_amd.h disagree"
+    assert lib.ldpc_amd_version() == 100
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.LdpcError) as ei:
+        pkg.Decoder(1, 3, [0, 0, 0], [0, 1, 2])
+    assert ei.value.code == pkg.capi.ENODEV
+    with pytest.raises(pkg.LdpcError):
+        pkg.LogDecoder.decode([[1, 1, 1]], [0, 0, 0], 0.1, 5)
+
+
+def test_product_code_never_touches_the_oracle():
+    pkgdir = os.path.join(ROOT, "ldpc-simulator_amd")
+    for dirpath, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), "%s mentions the oracle" % f
+
+
+def test_check_matrix_text_format(tmp_path, pkg):
+    io = pkg.check_matrix_io
+    H = np.array([[1, 0, 1, 0], [0, 1, 1, 0], [0, 0, 0, 1]], np.int32)
+    p = tmp_path / "h.txt"
+    io.save_dense(str(p), H)
+    # CheckMatrixIO.java:13-19: "m n" line, then "i j " pairs row-major, each followed by a space
+    assert p.read_text() == "3 4\n0 0 0 2 1 1 1 2 2 3 "
+    m, n, rows, cols = io.load_check_matrix(str(p))
+    assert (io.to_dense(m, n, rows, cols) == H).all()
+    # out-of-range pairs are ignored, a trailing unpaired integer is dropped, repeats collapse
+    # (CheckMatrixIO.java:37-45)
+    q = tmp_path / "q.txt"
+    q.write_text("2 3\n0 0 0 0 5 1 1 7 1 2 1")
+    m, n, rows, cols = io.load_check_matrix(str(q))
+    assert (m, n) == (2, 3) and list(zip(rows.tolist(), cols.tolist())) == [(0, 0), (1, 2)]
+    e = tmp_path / "e.txt"
+    e.write_text("")
+    assert io.load_check_matrix(str(e)) is None  # CheckMatrixIO.java:30
+
+
+def test_code_builders(pkg):
+    codes = pkg.codes
+    m, n, rows, cols = codes.gallager(1024, 8, 2, seed=1)
+    dc, dv = codes.degrees(m, n, rows, cols)
+    assert (m, n, rows.size) == (256, 1024, 2048) and (dc == 8).all() and (dv == 2).all()
+    H = pkg.check_matrix_io.to_dense(m, n, rows, cols)
+    # block 0 of GenerateMatrix.java:17-21: row i covers columns [8i, 8i+8)
+    for i in range(128):
+        assert H[i].nonzero()[0].tolist() == list(range(8 * i, 8 * i + 8))
+    # every block has exactly one 1 per column (GenerateMatrix.java:25-32)
+    assert (H[:128].sum(axis=0) == 1).all() and (H[128:].sum(axis=0) == 1).all()
+    with pytest.raises(ValueError):
+        codes.gallager(4096, 6, 3, seed=1)  # 4096 % 6 != 0, Divisibility.java:4-7
+    m, n, rows, cols = codes.regular_ldpc(4096, 3, 6, seed=1)
+    dc, dv = codes.degrees(m, n, rows, cols)
+    assert (m, rows.size) == (2048, 12288) and (dc == 6).all() and (dv == 3).all()
+    assert (np.diff(rows.astype(np.int64) * n + cols) > 0).all()  # row-major, no repeats
+    base, (m, n, rows, cols) = codes.nr_bg1_shaped(z=384, seed=1)
+    dc, dv = codes.degrees(m, n, rows, cols)
+    assert (m, n, rows.size) == (17664, 26112, 121344)
+    assert dc.min() == 3 and dc.max() == 19 and dv.min() == 1 and dv.max() == 30
+    # QC expansion rule of GenerateMatrix.java:139-150
+    b = np.array([[2, -1], [0, 1]])
+    m, n, rows, cols = codes.qc_expand(b, 3)
+    H = pkg.check_matrix_io.to_dense(m, n, rows, cols)
+    assert H[0, 2] == 1 and H[1, 0] == 1 and H[2, 1] == 1 and H[:3, 3:].sum() == 0
+    assert H[3, 0] == 1 and H[3, 4] == 1 and H[5, 3] == 1
+    base, _ = codes.random_qc(108, 5, 10, seed=3)
+    assert not codes.has_base_4cycle(base, 108)
+    assert ((base >= 0).sum(axis=0) >= 2).all() and ((base >= 0).sum(axis=1) >= 2).all()
+
+
+def test_shard_ranges_partition_the_frames(pkg):
+    for frames, world in ((10, 3), (1 << 20, 8), (5, 8), (0, 2)):
+        got = [pkg.sim.shard_range(100, frames, r, world) for r in range(world)]
+        assert sum(c for _, c in got) == frames
+        pos = 100
+        for start, count in got:
+            assert start == pos
+            pos += count
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+import ldpc_simulator_amd as L
+from oracle import oracle_capi as oc
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+m, n, rows, cols = L.codes.gallager(96, 8, 2, seed=3)
+g = oc.Graph(m, n, rows, cols)
+# CPU stand-in for Decoder.simulate so that the sharding and the reduction run without a GPU
+fn = lambda first, count: g.simulate(oc.CH_BSC_ALL, 0.04, 5, first, count, 20, threads=1)
+total = L.sim.simulate_sharded(fn, 1000, 301, 20, rank, world)
+whole = g.simulate(oc.CH_BSC_ALL, 0.04, 5, 1000, 301, 20, threads=1)
+assert (total == whole).all(), (total, whole)
+assert total[0] == 301
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_world_size_two_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out
+
+
+def test_rates_from_counters(pkg):
+    c = np.zeros(16 + 5, np.uint64)
+    c[0], c[1], c[2], c[4], c[8], c[9], c[10] = 100, 4, 12, 3, 300, 20, 50
+    r = pkg.sim.rates(c, m=8, n=24)
+    assert r["FER"] == 0.04 and r["IFER"] == 0.03 and r["IBER"] == 12 / (16 * 100)
+    assert r["avg_iters_correct"] == 300 / 96 and r["avg_iters_wrong"] == 5.0 and r["channel_BER"] == 50 / 1600

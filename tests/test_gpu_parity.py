@@ -22,8 +22,14 @@ def _syndrome_weight(H, hard):
 
 
 def _agreement(a, b):
-    """fraction of frames whose (hard, iters, synd) triples are identical"""
+    """fraction of frames whose (hard, iters, synd) triples are identical, and the rest"""
     same = (a[0] == b[0]).all(axis=1) & (a[1] == b[1]) & (a[2] == b[2])
+    return same.mean(), np.nonzero(~same)[0]
+
+
+def _hard_agreement(a, b):
+    """fraction of frames whose hard decisions are identical (the >= 99.99 % bar)"""
+    same = (a[0] == b[0]).all(axis=1)
     return same.mean(), np.nonzero(~same)[0]
 
 
@@ -104,10 +110,30 @@ def test_c2_awgn_early_exit(c2, oracle):
     got = c2["dec"].decode_batch(llr, 50, True)
     want = c2["g"].decode_llr_batch(llr, 50, True)
     frac, diff = _agreement(got, want)
+    hfrac, hdiff = _hard_agreement(got, want)
+    print("C2 2.0 dB early-exit: hard decisions differ on %d, (hard, iters, syndrome) on %d of %d frames; "
+          "iters gpu %s oracle %s" % (hdiff.size, diff.size, F, got[1][diff[:10]].tolist(), want[1][diff[:10]].tolist()))
+    assert hdiff.size == 0, (hfrac, hdiff[:10])   # 0 of 3000: consistent with the 99.99 % bar
     assert frac >= 0.999, (frac, diff[:10], got[1][diff[:10]], want[1][diff[:10]])
     H = _dense(m, n, c2["rows"], c2["cols"])
     assert (_syndrome_weight(H, got[0]) == got[2]).all()
-    print("C2 2.0 dB early-exit: %d of %d frames differ" % (diff.size, F))
+
+
+def test_c2_literal_tanh_rule_documented_divergence(c2, oracle, pkg):
+    """The literal fp32 tanh-product rule saturates at |beta| ~ 17 (double: ~ 38) and rounds
+    1 - tanh coarsely above |beta| ~ 10; it still decodes, but converges an iteration early or
+    late on a fraction of a percent of frames.  Kept selectable, not the default."""
+    m, n = c2["m"], c2["n"]
+    dec = pkg.Decoder(m, n, c2["rows"], c2["cols"])
+    dec.set_cn_rule(pkg.capi.CN_SUMPRODUCT_TANH)
+    F = 1500
+    llr = oracle.gen_awgn_llr(m, n, 2.0, seed=3, first_frame=0, frames=F)
+    got = dec.decode_batch(llr, 50, True)
+    want = c2["g"].decode_llr_batch(llr, 50, True)
+    frac, diff = _agreement(got, want)
+    hfrac, hdiff = _hard_agreement(got, want)
+    print("literal tanh rule: hard decisions differ on %d, triples on %d of %d frames" % (hdiff.size, diff.size, F))
+    assert hfrac >= 0.995 and frac >= 0.98
 
 
 def test_c2_fixed_iterations_four_frames_per_lane(c2, oracle):
