@@ -42,7 +42,8 @@ struct BpParams {
     float* ws_msg;           // [tiles][E][T]
     const float* ws_lam;     // [tiles][n][T]
     uint32_t* ws_bits;       // [tiles][nw][T] packed decisions, bit (j & 31) of word j >> 5
-    long long msg_stride, lam_stride, bits_stride;  // per-tile strides in elements
+    long long msg_tile, lam_tile, bits_tile;  // element offset from one tile to the next
+    long long msg_row, lam_row, bits_row;     // element offset from one edge / variable / word row to the next
     int tiles;               // tiles in this launch
     long long frame_base;    // batch index of frame 0 of tile 0
     long long frames_total;  // frames in the batch
@@ -50,6 +51,7 @@ struct BpParams {
     int32_t* out_iters;      // [frames_total] or null
     int32_t* out_synd;       // [frames_total] or null
     int lds_maxd;            // rows of LDS staging per wave and array (0 = no LDS path)
+    int skip;                // timing experiments only: bit 0 skips the CN sweeps, bit 1 the VN sweeps
 };
 
 // ---- vector access helpers: FPL consecutive floats / words per lane -------------------
@@ -150,103 +152,100 @@ __device__ __forceinline__ float phi(float x) {
 // factor is exactly 1 there, so its log-domain term is exactly 0.
 constexpr float kDoubleTanhSaturation = 38.1230949f;  // 55 ln 2
 
-// beta[0..D) -> alpha[0..D) in place, D a compile-time degree.
-template <int FPL, int D, int RULE>
-__device__ __forceinline__ void cn_compute(float (&b)[D][FPL]) {
+// beta[0..D) -> alpha[0..D) in place, D a compile-time degree.  The FPL frames of a lane are
+// independent; they are processed one after the other so that only one frame's prefix array is live.
+template <int D, int RULE>
+__device__ __forceinline__ void cn_compute1(float (&b)[D]) {
     if constexpr (RULE == kCnSumProduct) {
-        float pre[D][FPL];
+        float pre[D];
+        pre[0] = 1.0f;  // "double product = 1.0", LogDecoder.java:86
 #pragma unroll
-        for (int f = 0; f < FPL; ++f) pre[0][f] = 1.0f;  // "double product = 1.0", LogDecoder.java:86
+        for (int k = 0; k < D; ++k) {
+            const float t = tanh_half(b[k]);
+            b[k] = t;
+            if (k + 1 < D) pre[k + 1] = pre[k] * t;
+        }
+        float suf = 1.0f;
 #pragma unroll
-        for (int k = 0; k < D; ++k)
-#pragma unroll
-            for (int f = 0; f < FPL; ++f) {
-                const float t = tanh_half(b[k][f]);
-                b[k][f] = t;
-                if (k + 1 < D) pre[k + 1][f] = pre[k][f] * t;
-            }
-        float suf[FPL];
-#pragma unroll
-        for (int f = 0; f < FPL; ++f) suf[f] = 1.0f;
-#pragma unroll
-        for (int k = D - 1; k >= 0; --k)
-#pragma unroll
-            for (int f = 0; f < FPL; ++f) {
-                const float p = pre[k][f] * suf[f];
-                suf[f] *= b[k][f];
-                b[k][f] = atanh2(p);
-            }
+        for (int k = D - 1; k >= 0; --k) {
+            const float p = pre[k] * suf;
+            suf *= b[k];
+            b[k] = atanh2(p);
+        }
     } else if constexpr (RULE == kCnLogTanh) {
-        // same rule as above in the (sign, phi) domain; sums ascend like the products they stand for
-        float pre[D][FPL];
-        uint32_t psg[D][FPL];
+        // same rule in the (sign, phi) domain; sums ascend like the products they stand for.
+        // phi >= 0 and its prefix sums >= 0, so their sign bits carry sign(beta) and its prefix product.
+        float pre[D];
+        float run = 0.0f;
+        uint32_t rsg = 0u;
 #pragma unroll
-        for (int f = 0; f < FPL; ++f) { pre[0][f] = 0.0f; psg[0][f] = 0u; }
+        for (int k = 0; k < D; ++k) {
+            const float a = fabsf(b[k]);
+            const uint32_t sg = __float_as_uint(b[k]) & 0x80000000u;
+            const float ph = (a > kDoubleTanhSaturation) ? 0.0f : phi(a);
+            b[k] = __uint_as_float(__float_as_uint(ph) | sg);
+            pre[k] = __uint_as_float(__float_as_uint(run) | rsg);
+            run += ph;
+            rsg ^= sg;
+        }
+        float suf = 0.0f;
+        uint32_t ssg = 0u;
 #pragma unroll
-        for (int k = 0; k < D; ++k)
-#pragma unroll
-            for (int f = 0; f < FPL; ++f) {
-                const float a = fabsf(b[k][f]);
-                const uint32_t sg = __float_as_uint(b[k][f]) & 0x80000000u;
-                const float ph = (a > kDoubleTanhSaturation) ? 0.0f : phi(a);
-                b[k][f] = __uint_as_float(__float_as_uint(ph) | sg);  // phi >= 0: the sign bit carries sign(beta)
-                if (k + 1 < D) { pre[k + 1][f] = pre[k][f] + ph; psg[k + 1][f] = psg[k][f] ^ sg; }
-            }
-        float suf[FPL];
-        uint32_t ssg[FPL];
-#pragma unroll
-        for (int f = 0; f < FPL; ++f) { suf[f] = 0.0f; ssg[f] = 0u; }
-#pragma unroll
-        for (int k = D - 1; k >= 0; --k)
-#pragma unroll
-            for (int f = 0; f < FPL; ++f) {
-                const float ph = fabsf(b[k][f]);
-                const uint32_t sg = __float_as_uint(b[k][f]) & 0x80000000u;
-                const float mag = phi(pre[k][f] + suf[f]);
-                b[k][f] = __uint_as_float(__float_as_uint(mag) ^ psg[k][f] ^ ssg[f]);
-                suf[f] += ph;
-                ssg[f] ^= sg;
-            }
+        for (int k = D - 1; k >= 0; --k) {
+            const float ph = fabsf(b[k]);
+            const uint32_t sg = __float_as_uint(b[k]) & 0x80000000u;
+            const float mag = phi(fabsf(pre[k]) + suf);
+            b[k] = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(pre[k]) & 0x80000000u) ^ ssg);
+            suf += ph;
+            ssg ^= sg;
+        }
     } else {
         // MinSumDecoder.java:79-93: alpha = prod signum(beta) * min|beta| * 0.7 over k != j;
         // "minbata > |beta|" never selects a NaN, and Double.MAX_VALUE becomes FLT_MAX.
-        float ps[D][FPL], pm[D][FPL];
+        float ps[D], pm[D];
+        ps[0] = 1.0f;
+        pm[0] = 3.402823466e+38f;
 #pragma unroll
-        for (int f = 0; f < FPL; ++f) { ps[0][f] = 1.0f; pm[0][f] = 3.402823466e+38f; }
+        for (int k = 0; k + 1 < D; ++k) {
+            const float a = fabsf(b[k]);
+            ps[k + 1] = ps[k] * signum(b[k]);
+            pm[k + 1] = (pm[k] > a) ? a : pm[k];
+        }
+        float ss = 1.0f, sm = 3.402823466e+38f;
 #pragma unroll
-        for (int k = 0; k + 1 < D; ++k)
+        for (int k = D - 1; k >= 0; --k) {
+            const float a = fabsf(b[k]);
+            const float sg = signum(b[k]);
+            const float mn = (pm[k] > sm) ? sm : pm[k];
+            b[k] = ps[k] * ss * mn * 0.7f;
+            ss *= sg;
+            sm = (sm > a) ? a : sm;
+        }
+    }
+}
+
+template <int FPL, int D, int RULE>
+__device__ __forceinline__ void cn_compute(float (&b)[D][FPL]) {
 #pragma unroll
-            for (int f = 0; f < FPL; ++f) {
-                const float a = fabsf(b[k][f]);
-                ps[k + 1][f] = ps[k][f] * signum(b[k][f]);
-                pm[k + 1][f] = (pm[k][f] > a) ? a : pm[k][f];
-            }
-        float ss[FPL], sm[FPL];
+    for (int f = 0; f < FPL; ++f) {
+        float x[D];
 #pragma unroll
-        for (int f = 0; f < FPL; ++f) { ss[f] = 1.0f; sm[f] = 3.402823466e+38f; }
+        for (int k = 0; k < D; ++k) x[k] = b[k][f];
+        cn_compute1<D, RULE>(x);
 #pragma unroll
-        for (int k = D - 1; k >= 0; --k)
-#pragma unroll
-            for (int f = 0; f < FPL; ++f) {
-                const float a = fabsf(b[k][f]);
-                const float sg = signum(b[k][f]);
-                const float mn = (pm[k][f] > sm[f]) ? sm[f] : pm[k][f];
-                b[k][f] = ps[k][f] * ss[f] * mn * 0.7f;
-                ss[f] *= sg;
-                sm[f] = (sm[f] > a) ? a : sm[f];
-            }
+        for (int k = 0; k < D; ++k) b[k][f] = x[k];
     }
 }
 
 // One check of compile-time degree D.  `row` points at this lane's slot of the check's first
 // edge row; FIRST reads beta = lambda + 0.0 through the column indices instead.
 template <int FPL, int D, int RULE, bool FIRST>
-__device__ __forceinline__ void cn_row(float* row, const float* lam, const int* cols, int T) {
+__device__ __forceinline__ void cn_row(float* row, const float* lam, const int* cols, long long T, long long LT) {
     float b[D][FPL];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         if constexpr (FIRST) {
-            ldv<FPL>(lam + (long long)cols[k] * T, b[k]);
+            ldv<FPL>(lam + (long long)cols[k] * LT, b[k]);
 #pragma unroll
             for (int f = 0; f < FPL; ++f) b[k][f] += 0.0f;
         } else {
@@ -262,14 +261,14 @@ __device__ __forceinline__ void cn_row(float* row, const float* lam, const int* 
 // products of the row are staged in LDS as [k][lane] (conflict-free), then combined with
 // the running suffix product on the way back.
 template <int RULE, bool FIRST>
-__device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const int* cols, int T, int d,
-                                           float* lds, int cap, int lane) {
+__device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const int* cols, long long T, long long LT,
+                                           int d, float* lds, int cap, int lane) {
     float* st = lds + lane;                 // [k][64]: tanh (or beta for min-sum)
     float* sp = lds + (long long)cap * 64 + lane;  // [k][64]: exclusive prefix product / prefix min
     if constexpr (RULE == kCnSumProduct) {
         float pre = 1.0f;
         for (int k = 0; k < d; ++k) {
-            float b = FIRST ? (lam[(long long)cols[k] * T] + 0.0f) : row[(long long)k * T];
+            float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
             const float t = tanh_half(b);
             st[k * 64] = t;
             sp[k * 64] = pre;
@@ -286,7 +285,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
         float pre = 0.0f;
         uint32_t psg = 0u;
         for (int k = 0; k < d; ++k) {
-            float b = FIRST ? (lam[(long long)cols[k] * T] + 0.0f) : row[(long long)k * T];
+            float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
             const float a = fabsf(b);
             const uint32_t sg = __float_as_uint(b) & 0x80000000u;
             const float ph = (a > kDoubleTanhSaturation) ? 0.0f : phi(a);
@@ -309,7 +308,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
         // of row k is rebuilt from the staged beta on the way back (this path is rare).
         float pm = 3.402823466e+38f;
         for (int k = 0; k < d; ++k) {
-            float b = FIRST ? (lam[(long long)cols[k] * T] + 0.0f) : row[(long long)k * T];
+            float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
             st[k * 64] = b;
             sp[k * 64] = pm;
             const float a = fabsf(b);
@@ -361,7 +360,7 @@ __device__ __forceinline__ void vn_compute(float (&a)[D][FPL], const float (&lam
 }
 
 template <int FPL, int D>
-__device__ __forceinline__ void vn_col(float* msg, const float* lamrow, const int* edges, int T, bool write_beta,
+__device__ __forceinline__ void vn_col(float* msg, const float* lamrow, const int* edges, long long T, bool write_beta,
                                        float (&g)[FPL]) {
     float lam[FPL];
     ldv<FPL>(lamrow, lam);
@@ -383,7 +382,7 @@ __device__ __forceinline__ void vn_col(float* msg, const float* lamrow, const in
     }
 }
 
-__device__ __forceinline__ float vn_col_lds(float* msg, const float* lamrow, const int* edges, int T, int d,
+__device__ __forceinline__ float vn_col_lds(float* msg, const float* lamrow, const int* edges, long long T, int d,
                                             bool write_beta, float* lds, int cap, int lane) {
     float* sa = lds + lane;                        // alpha
     float* sp = lds + (long long)cap * 64 + lane;  // prefix sums
@@ -409,9 +408,9 @@ __device__ __forceinline__ float vn_col_lds(float* msg, const float* lamrow, con
 #define LDPC_CASE_CN(D)                                                              \
     case D:                                                                          \
         if constexpr (D <= (FPL == 1 ? kRegDegFpl1 : kRegDegFpl4))                   \
-            cn_row<FPL, D, RULE, FIRST>(row, lam, cols, T);                          \
+            cn_row<FPL, D, RULE, FIRST>(row, lam, cols, T, LT);                          \
         else if constexpr (FPL == 1)                                                 \
-            cn_row_lds<RULE, FIRST>(row, lam, cols, T, d, lds, cap, lane);           \
+            cn_row_lds<RULE, FIRST>(row, lam, cols, T, LT, d, lds, cap, lane);           \
         break;
 #define LDPC_CASE_VN(D)                                                              \
     case D:                                                                          \
@@ -422,8 +421,8 @@ __device__ __forceinline__ float vn_col_lds(float* msg, const float* lamrow, con
         break;
 
 template <int FPL, int RULE, bool FIRST>
-__device__ __forceinline__ void cn_dispatch(int d, float* row, const float* lam, const int* cols, int T, float* lds,
-                                            int cap, int lane) {
+__device__ __forceinline__ void cn_dispatch(int d, float* row, const float* lam, const int* cols, long long T,
+                                            long long LT, float* lds, int cap, int lane) {
     switch (d) {
         case 0: break;
         LDPC_CASE_CN(1) LDPC_CASE_CN(2) LDPC_CASE_CN(3) LDPC_CASE_CN(4)
@@ -437,7 +436,7 @@ __device__ __forceinline__ void cn_dispatch(int d, float* row, const float* lam,
                     LDPC_CASE_CN(21) LDPC_CASE_CN(22) LDPC_CASE_CN(23) LDPC_CASE_CN(24)
                     LDPC_CASE_CN(25) LDPC_CASE_CN(26) LDPC_CASE_CN(27) LDPC_CASE_CN(28)
                     LDPC_CASE_CN(29) LDPC_CASE_CN(30) LDPC_CASE_CN(31) LDPC_CASE_CN(32)
-                    default: cn_row_lds<RULE, FIRST>(row, lam, cols, T, d, lds, cap, lane); break;
+                    default: cn_row_lds<RULE, FIRST>(row, lam, cols, T, LT, d, lds, cap, lane); break;
                 }
             }
             break;
@@ -445,7 +444,7 @@ __device__ __forceinline__ void cn_dispatch(int d, float* row, const float* lam,
 }
 
 template <int FPL>
-__device__ __forceinline__ void vn_dispatch(int d, float* msg, const float* lamrow, const int* edges, int T,
+__device__ __forceinline__ void vn_dispatch(int d, float* msg, const float* lamrow, const int* edges, long long T,
                                             bool write_beta, float (&g)[FPL], float* lds, int cap, int lane) {
     switch (d) {
         LDPC_CASE_VN(0) LDPC_CASE_VN(1) LDPC_CASE_VN(2) LDPC_CASE_VN(3) LDPC_CASE_VN(4)
@@ -469,19 +468,126 @@ __device__ __forceinline__ void vn_dispatch(int d, float* msg, const float* lamr
 #undef LDPC_CASE_VN
 
 // ---- sweeps ------------------------------------------------------------------------------
-template <int FPL, int RULE, bool FIRST>
-__device__ __forceinline__ void cn_sweep(const BpParams& p, float* msg, const float* lam, int T, float* lds, int lane) {
+// Regular codes (every check of degree D): rows of check i are edges i*D .. i*D+D-1.  The loads of
+// check i+1 are issued before check i is computed and stored, so a wave always has one row set in
+// flight while it computes, and the wait for those loads never has to wait for the stores issued
+// after them (vector memory operations retire in issue order).
+template <int FPL, int D, bool FIRST>
+__device__ __forceinline__ void cn_load(const BpParams& p, const float* msg, const float* lam, int i,
+                                        float (&b)[D][FPL]) {
+    const long long e0 = (long long)i * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        if constexpr (FIRST) ldv<FPL>(lam + (long long)p.edge_col[e0 + k] * p.lam_row, b[k]);
+        else                 ldv<FPL>(msg + (e0 + k) * p.msg_row, b[k]);
+    }
+}
+
+template <int FPL, int D, int RULE, bool FIRST>
+__device__ __forceinline__ void cn_finish(const BpParams& p, float* msg, int i, float (&b)[D][FPL]) {
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) b[k][f] += 0.0f;  // lambda + the zero-initialised alpha of :57
+    }
+    cn_compute<FPL, D, RULE>(b);
+    const long long e0 = (long long)i * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) stv<FPL>(msg + (e0 + k) * p.msg_row, b[k]);
+}
+
+template <int FPL, int D, int RULE, bool FIRST>
+__device__ __forceinline__ void cn_sweep_regular(const BpParams& p, float* msg, const float* lam) {
+    float A[D][FPL], B[D][FPL];
+    const int m = p.m;
+    if (m > 0) cn_load<FPL, D, FIRST>(p, msg, lam, 0, A);
+    int i = 0;
+    for (; i + 1 < m; i += 2) {
+        cn_load<FPL, D, FIRST>(p, msg, lam, i + 1, B);
+        cn_finish<FPL, D, RULE, FIRST>(p, msg, i, A);
+        if (i + 2 < m) cn_load<FPL, D, FIRST>(p, msg, lam, i + 2, A);
+        cn_finish<FPL, D, RULE, FIRST>(p, msg, i + 1, B);
+    }
+    if (i < m) cn_finish<FPL, D, RULE, FIRST>(p, msg, i, A);
+}
+
+template <int FPL, int RULE, bool FIRST, int DC>
+__device__ __forceinline__ void cn_sweep(const BpParams& p, float* msg, const float* lam, float* lds, int lane) {
+    if constexpr (DC > 0) {
+        cn_sweep_regular<FPL, DC, RULE, FIRST>(p, msg, lam);
+        return;
+    }
     for (int i = 0; i < p.m; ++i) {
         const int e0 = p.row_ptr[i];
         const int d = p.row_ptr[i + 1] - e0;
-        cn_dispatch<FPL, RULE, FIRST>(d, msg + (long long)e0 * T, lam, p.edge_col + e0, T, lds, p.lds_maxd, lane);
+        cn_dispatch<FPL, RULE, FIRST>(d, msg + (long long)e0 * p.msg_row, lam, p.edge_col + e0, p.msg_row, p.lam_row, lds,
+                                      p.lds_maxd, lane);
     }
 }
 
 // beta for the next iteration + tentative decisions of this one (LogDecoder.java:67-79, :98-105)
-template <int FPL>
-__device__ __forceinline__ void vn_sweep(const BpParams& p, float* msg, const float* lam, uint32_t* bits, int T,
+template <int FPL, int D>
+struct VnBuf {
+    float a[D][FPL];
+    float lam[FPL];
+    long long off[D];
+};
+
+template <int FPL, int D>
+__device__ __forceinline__ void vn_load(const BpParams& p, const float* msg, const float* lam, int j, VnBuf<FPL, D>& b) {
+    const long long c0 = (long long)j * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) b.off[k] = (long long)p.col_edge[c0 + k] * p.msg_row;
+#pragma unroll
+    for (int k = 0; k < D; ++k) ldv<FPL>(msg + b.off[k], b.a[k]);
+    ldv<FPL>(lam + (long long)j * p.lam_row, b.lam);
+}
+
+template <int FPL, int D>
+__device__ __forceinline__ void vn_finish(const BpParams& p, float* msg, uint32_t* bits, int j, bool write_beta,
+                                          VnBuf<FPL, D>& b, uint32_t (&acc)[FPL]) {
+    float g[FPL];
+    vn_compute<FPL, D>(b.a, b.lam, g);
+    if (write_beta) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) stv<FPL>(msg + b.off[k], b.a[k]);
+    }
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) acc[f] |= (g[f] < 0.0f ? 1u : 0u) << (j & 31);  // "(gamma[j] < 0) ? 1 : 0", :104
+    if ((j & 31) == 31 || j == p.n - 1) {
+        stw<FPL>(bits + (long long)(j >> 5) * p.bits_row, acc);
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) acc[f] = 0u;
+    }
+}
+
+template <int FPL, int D>
+__device__ __forceinline__ void vn_sweep_regular(const BpParams& p, float* msg, const float* lam, uint32_t* bits,
+                                                 bool write_beta) {
+    VnBuf<FPL, D> A, B;
+    uint32_t acc[FPL];
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) acc[f] = 0u;
+    const int n = p.n;
+    if (n > 0) vn_load<FPL, D>(p, msg, lam, 0, A);
+    int j = 0;
+    for (; j + 1 < n; j += 2) {
+        vn_load<FPL, D>(p, msg, lam, j + 1, B);
+        vn_finish<FPL, D>(p, msg, bits, j, write_beta, A, acc);
+        if (j + 2 < n) vn_load<FPL, D>(p, msg, lam, j + 2, A);
+        vn_finish<FPL, D>(p, msg, bits, j + 1, write_beta, B, acc);
+    }
+    if (j < n) vn_finish<FPL, D>(p, msg, bits, j, write_beta, A, acc);
+}
+
+template <int FPL, int DV>
+__device__ __forceinline__ void vn_sweep(const BpParams& p, float* msg, const float* lam, uint32_t* bits,
                                          bool write_beta, float* lds, int lane) {
+    if constexpr (DV > 0) {
+        vn_sweep_regular<FPL, DV>(p, msg, lam, bits, write_beta);
+        return;
+    }
     uint32_t acc[FPL];
 #pragma unroll
     for (int f = 0; f < FPL; ++f) acc[f] = 0u;
@@ -489,11 +595,12 @@ __device__ __forceinline__ void vn_sweep(const BpParams& p, float* msg, const fl
         const int c0 = p.col_ptr[j];
         const int d = p.col_ptr[j + 1] - c0;
         float g[FPL];
-        vn_dispatch<FPL>(d, msg, lam + (long long)j * T, p.col_edge + c0, T, write_beta, g, lds, p.lds_maxd, lane);
+        vn_dispatch<FPL>(d, msg, lam + (long long)j * p.lam_row, p.col_edge + c0, p.msg_row, write_beta, g, lds,
+                         p.lds_maxd, lane);
 #pragma unroll
         for (int f = 0; f < FPL; ++f) acc[f] |= (g[f] < 0.0f ? 1u : 0u) << (j & 31);  // "(gamma[j] < 0) ? 1 : 0", :104
         if ((j & 31) == 31 || j == p.n - 1) {
-            stw<FPL>(bits + (long long)(j >> 5) * T, acc);
+            stw<FPL>(bits + (long long)(j >> 5) * p.bits_row, acc);
 #pragma unroll
             for (int f = 0; f < FPL; ++f) acc[f] = 0u;
         }
@@ -502,7 +609,7 @@ __device__ __forceinline__ void vn_sweep(const BpParams& p, float* msg, const fl
 
 // number of unsatisfied checks of the packed decisions (sumSyndro, LogDecoder.java:108-116)
 template <int FPL>
-__device__ __forceinline__ void syndrome_sweep(const BpParams& p, const uint32_t* bits, int T, int (&w)[FPL]) {
+__device__ __forceinline__ void syndrome_sweep(const BpParams& p, const uint32_t* bits, int (&w)[FPL]) {
 #pragma unroll
     for (int f = 0; f < FPL; ++f) w[f] = 0;
     for (int i = 0; i < p.m; ++i) {
@@ -513,7 +620,7 @@ __device__ __forceinline__ void syndrome_sweep(const BpParams& p, const uint32_t
         for (int e = e0; e < e1; ++e) {
             const int j = p.edge_col[e];
             uint32_t v[FPL];
-            ldw<FPL>(bits + (long long)(j >> 5) * T, v);
+            ldw<FPL>(bits + (long long)(j >> 5) * p.bits_row, v);
 #pragma unroll
             for (int f = 0; f < FPL; ++f) par[f] ^= v[f] >> (j & 31);
         }
@@ -523,8 +630,10 @@ __device__ __forceinline__ void syndrome_sweep(const BpParams& p, const uint32_t
 }
 
 // ---- the decoder: one wave = one tile, all iterations in one launch -------------------------
-template <int FPL, int RULE, bool EARLY>
-__global__ void __launch_bounds__(256, 4) bp_decode_kernel(BpParams p) {
+// DC / DV > 0: every check / variable has exactly that degree (pipelined sweeps); 0: any degrees.
+// WPS: waves per SIMD the register allocation must allow (4 -> 128 VGPRs, 2 -> 256 VGPRs).
+template <int FPL, int RULE, bool EARLY, int DC, int DV, int WPS>
+__global__ void __launch_bounds__(256, WPS) bp_decode_kernel(BpParams p) {
     extern __shared__ float lds_all[];
     static_assert(!EARLY || FPL == 1, "per-frame early termination masks whole lanes");
     const int lane = threadIdx.x & 63;
@@ -533,9 +642,9 @@ __global__ void __launch_bounds__(256, 4) bp_decode_kernel(BpParams p) {
     if (tile >= p.tiles) return;
     constexpr int T = kWave * FPL;
     float* lds = lds_all + (long long)wave_in_block * 2 * p.lds_maxd * 64;
-    float* msg = p.ws_msg + (long long)tile * p.msg_stride + lane * FPL;
-    const float* lam = p.ws_lam + (long long)tile * p.lam_stride + lane * FPL;
-    uint32_t* bits = p.ws_bits + (long long)tile * p.bits_stride + lane * FPL;
+    float* msg = p.ws_msg + (long long)tile * p.msg_tile + lane * FPL;
+    const float* lam = p.ws_lam + (long long)tile * p.lam_tile + lane * FPL;
+    uint32_t* bits = p.ws_bits + (long long)tile * p.bits_tile + lane * FPL;
     const long long frame0 = p.frame_base + (long long)tile * T + lane * FPL;
 
     if constexpr (EARLY) {
@@ -543,11 +652,11 @@ __global__ void __launch_bounds__(256, 4) bp_decode_kernel(BpParams p) {
         int iters = p.max_iters, synd = 0;
         for (int it = 0; it < p.max_iters; ++it) {
             if (active) {
-                if (it == 0) cn_sweep<FPL, RULE, true>(p, msg, lam, T, lds, lane);
-                else         cn_sweep<FPL, RULE, false>(p, msg, lam, T, lds, lane);
-                vn_sweep<FPL>(p, msg, lam, bits, T, true, lds, lane);
+                if (it == 0) cn_sweep<FPL, RULE, true, DC>(p, msg, lam, lds, lane);
+                else         cn_sweep<FPL, RULE, false, DC>(p, msg, lam, lds, lane);
+                vn_sweep<FPL, DV>(p, msg, lam, bits, true, lds, lane);
                 int w[1];
-                syndrome_sweep<1>(p, bits, T, w);
+                syndrome_sweep<1>(p, bits, w);
                 synd = w[0];
                 if (synd == 0) {  // "if(sumSyndro == 0) return ... l + 1", LogDecoder.java:117-119
                     iters = it + 1;
@@ -562,12 +671,14 @@ __global__ void __launch_bounds__(256, 4) bp_decode_kernel(BpParams p) {
         }
     } else {
         for (int it = 0; it < p.max_iters; ++it) {
-            if (it == 0) cn_sweep<FPL, RULE, true>(p, msg, lam, T, lds, lane);
-            else         cn_sweep<FPL, RULE, false>(p, msg, lam, T, lds, lane);
-            vn_sweep<FPL>(p, msg, lam, bits, T, it + 1 < p.max_iters, lds, lane);
+            if (!(p.skip & 1)) {
+                if (it == 0) cn_sweep<FPL, RULE, true, DC>(p, msg, lam, lds, lane);
+                else         cn_sweep<FPL, RULE, false, DC>(p, msg, lam, lds, lane);
+            }
+            if (!(p.skip & 2)) vn_sweep<FPL, DV>(p, msg, lam, bits, it + 1 < p.max_iters, lds, lane);
         }
         int w[FPL];
-        syndrome_sweep<FPL>(p, bits, T, w);
+        syndrome_sweep<FPL>(p, bits, w);
 #pragma unroll
         for (int f = 0; f < FPL; ++f) {
             if (frame0 + f < p.frames_total) {
@@ -577,5 +688,44 @@ __global__ void __launch_bounds__(256, 4) bp_decode_kernel(BpParams p) {
         }
     }
 }
+
+// One launcher per (DC, DV) specialisation, each compiled in its own translation unit.
+struct BpLaunch {
+    int fpl;     // frames per lane: 1, 2 or 4
+    int rule;    // kCnLogTanh / kCnSumProduct / kCnMinSum
+    bool early;  // per-frame early termination (fpl == 1 only)
+    int wps;     // 2 or 4 waves per SIMD (2 only with fpl == 4)
+    dim3 grid, block;
+    size_t lds_bytes;
+    hipStream_t stream;
+};
+
+template <int DC, int DV>
+inline void bp_launch_impl(const BpLaunch& l, const BpParams& p) {
+#define LDPC_LAUNCH_W(F, R, E, W) \
+    hipLaunchKernelGGL((bp_decode_kernel<F, R, E, DC, DV, W>), l.grid, l.block, l.lds_bytes, l.stream, p)
+#define LDPC_LAUNCH(F, R, E)                                         \
+    if (F == 4 && l.wps == 2) { LDPC_LAUNCH_W(F, R, E, (F == 4 ? 2 : 4)); } else { LDPC_LAUNCH_W(F, R, E, 4); }
+#define LDPC_BY_RULE(F, E)                                       \
+    switch (l.rule) {                                            \
+        case kCnMinSum: LDPC_LAUNCH(F, kCnMinSum, E); break;     \
+        case kCnSumProduct: LDPC_LAUNCH(F, kCnSumProduct, E); break; \
+        default: LDPC_LAUNCH(F, kCnLogTanh, E); break;           \
+    }
+    if (l.fpl == 1) {
+        if (l.early) { LDPC_BY_RULE(1, true) } else { LDPC_BY_RULE(1, false) }
+    } else if (l.fpl == 2) {
+        LDPC_BY_RULE(2, false)
+    } else {
+        LDPC_BY_RULE(4, false)
+    }
+#undef LDPC_BY_RULE
+#undef LDPC_LAUNCH
+#undef LDPC_LAUNCH_W
+}
+
+void bp_launch_generic(const BpLaunch& l, const BpParams& p);  // any degrees
+void bp_launch_6_3(const BpLaunch& l, const BpParams& p);      // every check degree 6, every variable degree 3
+void bp_launch_8_2(const BpLaunch& l, const BpParams& p);      // every check degree 8, every variable degree 2
 
 }  // namespace ldpc

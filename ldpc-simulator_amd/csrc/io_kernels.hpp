@@ -27,8 +27,8 @@ struct BscLlr {
 };
 
 template <class Src>
-__global__ void __launch_bounds__(256) load_lambda_kernel(Src src, float* ws_lam, long long lam_stride, int n, int T,
-                                                          long long frame_base, long long frames_total) {
+__global__ void __launch_bounds__(256) load_lambda_kernel(Src src, float* ws_lam, long long lam_tile, long long lam_row,
+                                                          int n, int T, long long frame_base, long long frames_total) {
     __shared__ float tile[64][65];
     const int chunks_per_tile = T >> 6;
     const int tile_id = blockIdx.x / chunks_per_tile;
@@ -46,19 +46,19 @@ __global__ void __launch_bounds__(256) load_lambda_kernel(Src src, float* ws_lam
         tile[fr][tx] = v;
     }
     __syncthreads();
-    float* out = ws_lam + (long long)tile_id * lam_stride;
+    float* out = ws_lam + (long long)tile_id * lam_tile;
 #pragma unroll 4
     for (int r = 0; r < 16; ++r) {
         const int jj = ty * 16 + r;
         const int j = j0 + jj;
-        if (j < n) out[(long long)j * T + t0 + tx] = tile[tx][jj];
+        if (j < n) out[(long long)j * lam_row + t0 + tx] = tile[tx][jj];
     }
 }
 
 // ---- packed decisions -> hard[frame][j] bytes ---------------------------------------------------
-__global__ void __launch_bounds__(256) unpack_hard_kernel(const uint32_t* ws_bits, long long bits_stride, int n, int T,
-                                                          long long frame_base, long long frames_in_launch,
-                                                          uint8_t* hard) {
+__global__ void __launch_bounds__(256) unpack_hard_kernel(const uint32_t* ws_bits, long long bits_tile, long long bits_row,
+                                                          int n, int T, long long frame_base,
+                                                          long long frames_in_launch, uint8_t* hard) {
     const int n4 = (n + 3) >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long fl = idx / n4;  // frame within the launch
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) unpack_hard_kernel(const uint32_t* ws_bit
     const int j = (int)(idx % n4) << 2;
     const long long tile = fl / T;
     const int t = (int)(fl % T);
-    const uint32_t w = ws_bits[tile * bits_stride + (long long)(j >> 5) * T + t] >> (j & 31);
+    const uint32_t w = ws_bits[tile * bits_tile + (long long)(j >> 5) * bits_row + t] >> (j & 31);
     uint8_t* o = hard + (frame_base + fl) * n + j;
     if ((n & 3) == 0) {
         *reinterpret_cast<uchar4*>(o) = make_uchar4(w & 1u, (w >> 1) & 1u, (w >> 2) & 1u, (w >> 3) & 1u);

@@ -24,6 +24,7 @@ struct ldpc_amd_ctx {
     int m = 0, n = 0, nw = 0;
     long long E = 0;
     int max_dc = 0, max_dv = 0;
+    int reg_dc = 0, reg_dv = 0;  // the common degree when every check / variable has it, else 0
     int cn_rule = LDPC_AMD_CN_SUMPRODUCT;
     int* d_row_ptr = nullptr;
     int* d_edge_col = nullptr;
@@ -112,8 +113,19 @@ void build_graph(ldpc_amd_ctx* c, long long nnz, const int32_t* rows, const int3
     std::vector<int> fill(c->h_col_ptr.begin(), c->h_col_ptr.end() - 1);
     for (long long e = 0; e < E; ++e) c->h_col_edge[(size_t)fill[(size_t)c->h_edge_col[(size_t)e]]++] = (int)e;
     c->max_dc = c->max_dv = 0;
-    for (int i = 0; i < m; ++i) c->max_dc = std::max(c->max_dc, c->h_row_ptr[(size_t)i + 1] - c->h_row_ptr[(size_t)i]);
-    for (int j = 0; j < n; ++j) c->max_dv = std::max(c->max_dv, c->h_col_ptr[(size_t)j + 1] - c->h_col_ptr[(size_t)j]);
+    int min_dc = 1 << 30, min_dv = 1 << 30;
+    for (int i = 0; i < m; ++i) {
+        const int d = c->h_row_ptr[(size_t)i + 1] - c->h_row_ptr[(size_t)i];
+        c->max_dc = std::max(c->max_dc, d);
+        min_dc = std::min(min_dc, d);
+    }
+    for (int j = 0; j < n; ++j) {
+        const int d = c->h_col_ptr[(size_t)j + 1] - c->h_col_ptr[(size_t)j];
+        c->max_dv = std::max(c->max_dv, d);
+        min_dv = std::min(min_dv, d);
+    }
+    c->reg_dc = (m > 0 && min_dc == c->max_dc) ? c->max_dc : 0;
+    c->reg_dv = (n > 0 && min_dv == c->max_dv) ? c->max_dv : 0;
 }
 
 int ensure_stage(ldpc_amd_ctx* c, int slot, size_t bytes) {
@@ -139,23 +151,22 @@ struct SrcArgs {
     float l0, l1;
 };
 
-template <int FPL>
-int launch_bp(ldpc_amd_ctx* c, const BpParams& p, bool early, int wpb, size_t lds_bytes, hipStream_t s) {
-    const dim3 grid((unsigned)((p.tiles + wpb - 1) / wpb)), block((unsigned)(64 * wpb));
-#define LDPC_LAUNCH(F, R, EARLY) hipLaunchKernelGGL((bp_decode_kernel<F, R, EARLY>), grid, block, lds_bytes, s, p)
-#define LDPC_BY_RULE(F, EARLY)                                            \
-    switch (c->cn_rule) {                                                 \
-        case LDPC_AMD_CN_MINSUM: LDPC_LAUNCH(F, kCnMinSum, EARLY); break; \
-        case LDPC_AMD_CN_SUMPRODUCT_TANH: LDPC_LAUNCH(F, kCnSumProduct, EARLY); break; \
-        default: LDPC_LAUNCH(F, kCnLogTanh, EARLY); break;                \
-    }
-    if constexpr (FPL == 1) {
-        if (early) { LDPC_BY_RULE(1, true) } else { LDPC_BY_RULE(1, false) }
-    } else {
-        LDPC_BY_RULE(FPL, false)
-    }
-#undef LDPC_BY_RULE
-#undef LDPC_LAUNCH
+int launch_bp(ldpc_amd_ctx* c, const BpParams& p, int fpl, bool early, int wpb, size_t lds_bytes, bool pipelined,
+              hipStream_t s) {
+    BpLaunch l;
+    l.fpl = fpl;
+    l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
+             : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnLogTanh;
+    l.early = early;
+    l.wps = fpl == 4 ? 2 : 4;  // 4 frames per lane need ~180 VGPRs to stay out of scratch
+    if (const char* env = getenv("LDPC_AMD_WPS")) l.wps = atoi(env) == 2 ? 2 : 4;
+    l.grid = dim3((unsigned)((p.tiles + wpb - 1) / wpb));
+    l.block = dim3((unsigned)(64 * wpb));
+    l.lds_bytes = lds_bytes;
+    l.stream = s;
+    if (pipelined && c->reg_dc == 6 && c->reg_dv == 3) bp_launch_6_3(l, p);
+    else if (pipelined && c->reg_dc == 8 && c->reg_dv == 2) bp_launch_8_2(l, p);
+    else bp_launch_generic(l, p);
     LDPC_HIP(c, hipGetLastError());
     return LDPC_AMD_OK;
 }
@@ -220,14 +231,27 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     BpParams p{};
     p.m = c->m; p.n = n; p.nw = c->nw;
     p.row_ptr = c->d_row_ptr; p.edge_col = c->d_edge_col; p.col_ptr = c->d_col_ptr; p.col_edge = c->d_col_edge;
-    p.msg_stride = c->E * T; p.lam_stride = (long long)n * T; p.bits_stride = (long long)c->nw * T;
+    // layout 0: [tile][row][T]  (a tile's rows are contiguous)
+    // layout 1: [row][tile][T]  (the same row of neighbouring tiles is contiguous)
+    int layout = 0;
+    if (const char* env = getenv("LDPC_AMD_LAYOUT")) layout = atoi(env) ? 1 : 0;
+    if (layout == 0) {
+        p.msg_row = p.lam_row = p.bits_row = T;
+        p.msg_tile = c->E * T; p.lam_tile = (long long)n * T; p.bits_tile = (long long)c->nw * T;
+    } else {
+        p.msg_row = p.lam_row = p.bits_row = tiles_per_round * T;
+        p.msg_tile = p.lam_tile = p.bits_tile = T;
+    }
     float* ws_msg = (float*)c->ws;
-    float* ws_lam = ws_msg + (size_t)tiles_per_round * p.msg_stride;
-    uint32_t* ws_bits = (uint32_t*)(ws_lam + (size_t)tiles_per_round * p.lam_stride);
+    float* ws_lam = ws_msg + (size_t)tiles_per_round * c->E * T;
+    uint32_t* ws_bits = (uint32_t*)(ws_lam + (size_t)tiles_per_round * n * T);
     p.ws_msg = ws_msg; p.ws_lam = ws_lam; p.ws_bits = ws_bits;
     p.frames_total = frames; p.max_iters = max_iters;
     p.out_iters = d_iters; p.out_synd = d_synd;
     p.lds_maxd = lds_maxd;
+    if (const char* env = getenv("LDPC_AMD_SKIP")) p.skip = atoi(env);  // timing experiments only
+    bool pipelined = true;
+    if (const char* env = getenv("LDPC_AMD_NOPIPE")) pipelined = atoi(env) == 0;  // A/B: per-row dispatch kernels
 
     for (long long r = 0; r < rounds; ++r) {
         const long long tile0 = r * tiles_per_round;
@@ -240,21 +264,17 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             const dim3 grid((unsigned)(tiles * (T / 64)), (unsigned)((n + 63) / 64)), block(256);
             if (src.kind == Src::Float) {
                 hipLaunchKernelGGL((load_lambda_kernel<FloatLlr>), grid, block, 0, s, FloatLlr{src.llr}, ws_lam,
-                                   p.lam_stride, n, T, frame_base, frames);
+                                   p.lam_tile, p.lam_row, n, T, frame_base, frames);
             } else {
                 hipLaunchKernelGGL((load_lambda_kernel<BscLlr>), grid, block, 0, s,
-                                   BscLlr{src.r, src.l0, src.l1, n - c->m}, ws_lam, p.lam_stride, n, T, frame_base,
-                                   frames);
+                                   BscLlr{src.r, src.l0, src.l1, n - c->m}, ws_lam, p.lam_tile, p.lam_row, n, T,
+                                   frame_base, frames);
             }
             LDPC_HIP(c, hipGetLastError());
         }
         const bool timed = r < 256;
         if (timed) LDPC_HIP(c, hipEventRecord(c->ev[(size_t)(2 * r)], s));
-        int rc;
-        if (fpl == 4) rc = launch_bp<4>(c, p, early, wpb, lds_bytes, s);
-        else if (fpl == 2) rc = launch_bp<2>(c, p, early, wpb, lds_bytes, s);
-        else rc = launch_bp<1>(c, p, early, wpb, lds_bytes, s);
-        if (rc) return rc;
+        if (int rc = launch_bp(c, p, fpl, early, wpb, lds_bytes, pipelined, s)) return rc;
         if (timed) {
             LDPC_HIP(c, hipEventRecord(c->ev[(size_t)(2 * r + 1)], s));
             c->timed_launches++;
@@ -264,8 +284,8 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             const long long n4 = (n + 3) / 4;
             const long long threads = frames_here * n4;
             const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
-            hipLaunchKernelGGL(unpack_hard_kernel, grid, block, 0, s, ws_bits, p.bits_stride, n, T, frame_base,
-                               frames_here, d_hard);
+            hipLaunchKernelGGL(unpack_hard_kernel, grid, block, 0, s, ws_bits, p.bits_tile, p.bits_row, n, T,
+                               frame_base, frames_here, d_hard);
             LDPC_HIP(c, hipGetLastError());
         }
     }
