@@ -49,7 +49,7 @@ def cpu_baseline(code, ebn0_db, iters, budget_s):
     t0 = time.perf_counter()
     g.decode_llr_batch(llr, iters, False, threads=threads)
     dt = time.perf_counter() - t0
-    frames = int(max(probe, min(8192, budget_s / max(dt / probe, 1e-6))))
+    frames = int(max(probe, min(65536, budget_s / max(dt / probe, 1e-6))))
     frames -= frames % threads
     llr = oc.gen_awgn_llr(m, n, ebn0_db, 0x5EED, 0, frames)
     t0 = time.perf_counter()
@@ -63,6 +63,24 @@ def cpu_baseline(code, ebn0_db, iters, budget_s):
         "sample": "%d frames of the same (3,6) n=%d code, %d fixed iterations, double precision, "
                   "sparse state, %d OpenMP threads, %.1f s" % (frames, n, iters, threads, dt),
     }
+
+
+def measured_traffic(kernel_prefix, frames, iters, n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/<round>/*hbm_traffic.json; FETCH_SIZE and WRITE_SIZE collected in separate passes,
+    FETCH_SIZE doubled as gfx950 requires), if one exists for exactly this workload."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*hbm_traffic.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        w = d.get("workload", {"frames": 1 << 20, "iters": 50, "n": 4096})
+        if d.get("kernel", "").find(kernel_prefix) >= 0 and (w["frames"], w["iters"], w["n"]) == (frames, iters, n):
+            best = d["hbm_bytes_per_launch"]
+    return best
 
 
 def main():
@@ -174,7 +192,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": measured_traffic("bp_decode_kernel", F, iters, n),
             "kernel": "bp_decode_kernel",
             "launch_ms": launch_s * 1e3,
             "algorithmic_bytes_per_launch": frames_per_launch * b_frame,
