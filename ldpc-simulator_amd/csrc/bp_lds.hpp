@@ -1,0 +1,222 @@
+// Frame-resident flooding belief propagation for gfx950: one workgroup decodes one frame whose whole
+// message state lives in LDS, so HBM sees only the channel LLRs in and the hard decisions out.
+//
+// Used for regular codes whose state fits on chip (E + n floats <= ~78 KiB, two workgroups per CU).
+// The arithmetic is the same code as the streaming kernels (cn_compute1 / vn_compute in
+// bp_kernels.hpp): same neighbour order, same prefix x suffix leave-one-out, so both engines return
+// identical bits.  What changes is the mapping:
+//   * thread t owns checks t, t+NT, ... in the CN phase and variables t, t+NT, ... in the VN phase
+//     (LogDecoder.java:82-95 and :67-79, :98-105), with a workgroup barrier between the phases;
+//   * msg[e] (CSR edge order) is read/written in place: a check's DC messages are DC consecutive
+//     floats, a variable's DV messages are gathered through its edge ids, which stay in registers for
+//     the whole decode;
+//   * a frame that reaches a zero syndrome leaves at once (LogDecoder.java:117-119): the workgroup
+//     ends and the next frame's workgroup takes its place, so early termination costs no idle lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bp_kernels.hpp"
+
+namespace ldpc {
+
+constexpr int kLdsMaxCpt = 4;  // checks per thread
+constexpr int kLdsMaxVpt = 8;  // variables per thread
+
+struct LdsParams {
+    int m, n, nw;
+    long long E;
+    const int* edge_col;   // [E]
+    const int* col_edge;   // [E]
+    const float* llr;      // [frames][n] channel LLRs, or null
+    const uint8_t* r;      // [frames][n] hard received words (then lambda = +-l0 / +-l1), or null
+    float l0, l1;
+    int g_length;          // n - m
+    long long frames;
+    int max_iters;
+    uint8_t* hard;         // [frames][n]
+    int32_t* out_iters;    // [frames] or null
+    int32_t* out_synd;     // [frames] or null
+};
+
+template <int DC>
+__device__ __forceinline__ void lds_load_row(const float* p, float (&x)[DC]) {
+    if constexpr (DC % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < DC / 2; ++q) {
+            const float2 v = reinterpret_cast<const float2*>(p)[q];
+            x[2 * q] = v.x;
+            x[2 * q + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < DC; ++k) x[k] = p[k];
+    }
+}
+template <int DC>
+__device__ __forceinline__ void lds_store_row(float* p, const float (&x)[DC]) {
+    if constexpr (DC % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < DC / 2; ++q) reinterpret_cast<float2*>(p)[q] = make_float2(x[2 * q], x[2 * q + 1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < DC; ++k) p[k] = x[k];
+    }
+}
+
+// number of unsatisfied checks of the decisions in `bits` (sumSyndro, LogDecoder.java:108-116)
+template <int DC>
+__device__ __forceinline__ int lds_syndrome(const LdsParams& p, const uint32_t* bits, int* red, int t, int nt) {
+    int cnt = 0;
+    for (int i = t; i < p.m; i += nt) {
+        uint32_t par = 0u;
+#pragma unroll
+        for (int k = 0; k < DC; ++k) {
+            const int j = p.edge_col[(long long)i * DC + k];
+            par ^= bits[j >> 5] >> (j & 31);
+        }
+        cnt += (int)(par & 1u);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((t & 63) == 0 && cnt) atomicAdd(red, cnt);
+    __syncthreads();
+    const int total = *red;
+    __syncthreads();
+    if (t == 0) *red = 0;
+    return total;
+}
+
+template <int DC, int DV, int RULE, bool EARLY>
+__global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
+    extern __shared__ float smem[];
+    float* msg = smem;                                   // [E]
+    float* lam = smem + p.E;                             // [n]
+    uint32_t* bits = reinterpret_cast<uint32_t*>(lam + p.n);  // [nw]
+    int* red = reinterpret_cast<int*>(bits + p.nw);      // syndrome accumulator
+    const int t = threadIdx.x, nt = blockDim.x;
+    const long long frame = blockIdx.x;
+    if (frame >= p.frames) return;
+
+    // this thread's variables and their edge slots (byte-free element offsets into msg)
+    int off[kLdsMaxVpt][DV];
+#pragma unroll
+    for (int v = 0; v < kLdsMaxVpt; ++v) {
+        const int j = t + v * nt;
+#pragma unroll
+        for (int k = 0; k < DV; ++k) off[v][k] = (j < p.n) ? p.col_edge[(long long)j * DV + k] : 0;
+    }
+    // channel LLRs of the frame -> LDS
+    if (p.llr) {
+        const float* src = p.llr + frame * p.n;
+        for (int j = t; j < p.n; j += nt) lam[j] = src[j];
+    } else {
+        const uint8_t* src = p.r + frame * p.n;
+        for (int j = t; j < p.n; j += nt) {
+            const float mag = (j < p.g_length) ? p.l0 : p.l1;  // LogDecoder.java:49-54
+            lam[j] = (src[j] == 0) ? mag : -mag;
+        }
+    }
+    if (t == 0) *red = 0;
+    __syncthreads();
+    // beta of the first iteration: lambda + the zero-initialised alpha (LogDecoder.java:57, :70-77)
+    for (long long e = t; e < p.E; e += nt) msg[e] = lam[p.edge_col[e]] + 0.0f;
+    __syncthreads();
+
+    int iters = p.max_iters, synd = 0;
+    for (int it = 0; it < p.max_iters; ++it) {
+        // check nodes: beta -> alpha in place
+#pragma unroll
+        for (int c = 0; c < kLdsMaxCpt; ++c) {
+            const int i = t + c * nt;
+            if (i < p.m) {
+                float x[DC];
+                lds_load_row<DC>(msg + (long long)i * DC, x);
+                cn_compute1<DC, RULE>(x);
+                lds_store_row<DC>(msg + (long long)i * DC, x);
+            }
+        }
+        __syncthreads();
+        // variable nodes: alpha -> beta in place, posterior sign -> decision bit
+        const bool write_beta = EARLY || (it + 1 < p.max_iters);
+#pragma unroll
+        for (int v = 0; v < kLdsMaxVpt; ++v) {
+            const int j = t + v * nt;
+            if (j < p.n) {
+                float a[DV][1], l[1], g[1];
+#pragma unroll
+                for (int k = 0; k < DV; ++k) a[k][0] = msg[off[v][k]];
+                l[0] = lam[j];
+                vn_compute<1, DV>(a, l, g);
+                if (write_beta) {
+#pragma unroll
+                    for (int k = 0; k < DV; ++k) msg[off[v][k]] = a[k][0];
+                }
+                if (EARLY || it + 1 == p.max_iters) {
+                    const unsigned long long mask = __ballot(g[0] < 0.0f);  // "(gamma[j] < 0) ? 1 : 0", :104
+                    if ((t & 63) == 0) {
+                        bits[j >> 5] = (uint32_t)mask;
+                        if (((j >> 5) + 1) < p.nw) bits[(j >> 5) + 1] = (uint32_t)(mask >> 32);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if constexpr (EARLY) {
+            synd = lds_syndrome<DC>(p, bits, red, t, nt);
+            if (synd == 0) {  // LogDecoder.java:117-119
+                iters = it + 1;
+                break;
+            }
+        }
+    }
+    if constexpr (!EARLY) synd = lds_syndrome<DC>(p, bits, red, t, nt);
+
+    uint8_t* out = p.hard + frame * p.n;
+    if ((p.n & 3) == 0) {
+        for (int j4 = t; j4 < (p.n >> 2); j4 += nt) {
+            const int j = j4 << 2;
+            const uint32_t w = bits[j >> 5] >> (j & 31);
+            reinterpret_cast<uchar4*>(out)[j4] = make_uchar4(w & 1u, (w >> 1) & 1u, (w >> 2) & 1u, (w >> 3) & 1u);
+        }
+    } else {
+        for (int j = t; j < p.n; j += nt) out[j] = (uint8_t)((bits[j >> 5] >> (j & 31)) & 1u);
+    }
+    if (t == 0) {
+        if (p.out_iters) p.out_iters[frame] = iters;
+        if (p.out_synd) p.out_synd[frame] = synd;
+    }
+}
+
+struct LdsLaunch {
+    int rule;
+    bool early;
+    int threads;
+    size_t lds_bytes;
+    hipStream_t stream;
+};
+
+template <int DC, int DV>
+inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
+    const dim3 grid((unsigned)p.frames), block((unsigned)l.threads);
+#define LDPC_LDS(R, E)                                                                                       \
+    do {                                                                                                     \
+        auto k = bp_lds_kernel<DC, DV, R, E>;                                                                \
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                           (int)l.lds_bytes);                                                \
+        if (e != hipSuccess) return e;                                                                       \
+        hipLaunchKernelGGL(k, grid, block, l.lds_bytes, l.stream, p);                                        \
+    } while (0)
+    switch (l.rule) {
+        case kCnMinSum: if (l.early) LDPC_LDS(kCnMinSum, true); else LDPC_LDS(kCnMinSum, false); break;
+        case kCnSumProduct: if (l.early) LDPC_LDS(kCnSumProduct, true); else LDPC_LDS(kCnSumProduct, false); break;
+        default: if (l.early) LDPC_LDS(kCnLogTanh, true); else LDPC_LDS(kCnLogTanh, false); break;
+    }
+#undef LDPC_LDS
+    return hipGetLastError();
+}
+
+hipError_t bp_lds_launch_6_3(const LdsLaunch& l, const LdsParams& p);
+hipError_t bp_lds_launch_8_2(const LdsLaunch& l, const LdsParams& p);
+
+}  // namespace ldpc

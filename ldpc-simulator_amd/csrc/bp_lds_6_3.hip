@@ -1,0 +1,6 @@
+// Frame-resident (LDS) message-passing kernels, every check degree 6, every variable degree 3.
+#include "bp_lds.hpp"
+
+namespace ldpc {
+hipError_t bp_lds_launch_6_3(const LdsLaunch& l, const LdsParams& p) { return bp_lds_launch_impl<6, 3>(l, p); }
+}  // namespace ldpc

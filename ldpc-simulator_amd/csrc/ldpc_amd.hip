@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "bp_kernels.hpp"
+#include "bp_lds.hpp"
 #include "io_kernels.hpp"
 
 using namespace ldpc;
@@ -185,9 +186,45 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         if (d_synd) LDPC_HIP(c, hipMemsetAsync(d_synd, 0, (size_t)frames * 4, s));
         return LDPC_AMD_OK;
     }
+    const bool early = early_term != 0;
+    // Frame-resident engine: regular code whose messages + LLRs fit twice into a CU's LDS.
+    {
+        const bool shape = (c->reg_dc == 6 && c->reg_dv == 3) || (c->reg_dc == 8 && c->reg_dv == 2);
+        int nt = ((n + kLdsMaxVpt - 1) / kLdsMaxVpt + 63) / 64 * 64;
+        const size_t lds_bytes = ((size_t)c->E + (size_t)n + (size_t)c->nw + 4) * sizeof(float);
+        bool use = shape && nt <= 512 && (long long)kLdsMaxCpt * nt >= c->m && lds_bytes <= 80 * 1024 &&
+                   frames <= 0x7fffffffll;
+        if (const char* env = getenv("LDPC_AMD_ENGINE")) {
+            if (!strcmp(env, "stream")) use = false;
+        }
+        if (use) {
+            LdsParams q{};
+            q.m = c->m; q.n = n; q.nw = c->nw; q.E = c->E;
+            q.edge_col = c->d_edge_col; q.col_edge = c->d_col_edge;
+            q.llr = src.kind == Src::Float ? src.llr : nullptr;
+            q.r = src.kind == Src::Bsc ? src.r : nullptr;
+            q.l0 = src.l0; q.l1 = src.l1; q.g_length = n - c->m;
+            q.frames = frames; q.max_iters = max_iters;
+            q.hard = d_hard; q.out_iters = d_iters; q.out_synd = d_synd;
+            LdsLaunch l;
+            l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
+                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnLogTanh;
+            l.early = early; l.threads = nt; l.lds_bytes = lds_bytes; l.stream = s;
+            while (c->ev.size() < 2) {
+                hipEvent_t e;
+                LDPC_HIP(c, hipEventCreate(&e));
+                c->ev.push_back(e);
+            }
+            LDPC_HIP(c, hipEventRecord(c->ev[0], s));
+            LDPC_HIP(c, c->reg_dc == 6 ? bp_lds_launch_6_3(l, q) : bp_lds_launch_8_2(l, q));
+            LDPC_HIP(c, hipEventRecord(c->ev[1], s));
+            c->timed_launches = 1;
+            c->timed_frames = frames;
+            return LDPC_AMD_OK;
+        }
+    }
     const int maxdeg = std::max(c->max_dc, c->max_dv);
     if (maxdeg > kLdsMaxDegree) return fail(c, LDPC_AMD_ELIMIT, "node degree above 128 is not supported");
-    const bool early = early_term != 0;
     int fpl = (!early && maxdeg <= kRegDegFpl4) ? 4 : 1;
     if (const char* env = getenv("LDPC_AMD_FPL")) {
         const int v = atoi(env);

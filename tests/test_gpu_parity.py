@@ -8,7 +8,25 @@ resolve that, and the disagreeing frames are itemised in the assertion message.
 import numpy as np
 import pytest
 
+import os
+
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["resident", "stream"])
+def engine(request):
+    """Regular codes that fit in LDS run the frame-resident engine by default; every test also runs
+    with the frame-major streaming engine forced (LDPC_AMD_ENGINE=stream)."""
+    old = os.environ.get("LDPC_AMD_ENGINE")
+    if request.param == "stream":
+        os.environ["LDPC_AMD_ENGINE"] = "stream"
+    else:
+        os.environ.pop("LDPC_AMD_ENGINE", None)
+    yield request.param
+    if old is None:
+        os.environ.pop("LDPC_AMD_ENGINE", None)
+    else:
+        os.environ["LDPC_AMD_ENGINE"] = old
 
 
 def _dense(m, n, rows, cols):
@@ -169,6 +187,24 @@ def test_batch_split_and_rerun_invariance(c2, oracle):
     c2["dec"].set_workspace_limit(0)
     for x, y in zip(f1, f2):
         assert (x == y).all()
+
+
+def test_engines_return_identical_bits(c1, c2, oracle, engine):
+    """Both engines run the same arithmetic in the same order, so their outputs are equal bit for
+    bit, converged or not."""
+    if engine != "resident":
+        pytest.skip("comparison runs once")
+    for c, ebn0, F in ((c2, 1.2, 1500), (c1, 4.0, 1500)):
+        llr = oracle.gen_awgn_llr(c["m"], c["n"], ebn0, seed=12, first_frame=0, frames=F)
+        for early, L in ((True, 30), (False, 9)):
+            os.environ.pop("LDPC_AMD_ENGINE", None)
+            a = c["dec"].decode_batch(llr, L, early)
+            os.environ["LDPC_AMD_ENGINE"] = "stream"
+            b = c["dec"].decode_batch(llr, L, early)
+            os.environ.pop("LDPC_AMD_ENGINE", None)
+            for x, y in zip(a, b):
+                assert (x == y).all(), (early, L)
+            assert (a[2] > 0).any()
 
 
 def test_irregular_degrees_register_and_lds_paths(pkg, oracle):

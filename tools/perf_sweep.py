@@ -18,11 +18,12 @@ d_it = torch.empty(F, dtype=torch.int32, device="cuda")
 d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
 b_frame = iters * (4 * dec.E * 4 + n * 4)
-variants = [tuple(v.split(":")) for v in os.environ.get("SWEEP_VARIANTS", "0:4:4:0,0:4:2:0,0:2:4:0,1:4:4:0,1:4:2:0,0:4:4:1,0:4:2:1,0:4:4:2,0:4:2:2").split(",")]
+variants = [tuple(v.split(":")) for v in os.environ.get("SWEEP_VARIANTS", "0:4:2:0:stream,0:4:2:0:lds,2:4:2:0:lds,1:4:2:0:lds").split(",")]
 names = {0: "logtanh", 1: "minsum", 2: "tanh"}
 res = {}
 for r in range(rounds):
-    for rule, fpl, wps, skip in variants:
+    for rule, fpl, wps, skip, eng in variants:
+        os.environ["LDPC_AMD_ENGINE"] = eng
         layout = wps
         os.environ["LDPC_AMD_WPS"] = wps
         os.environ["LDPC_AMD_SKIP"] = skip
@@ -30,10 +31,10 @@ for r in range(rounds):
         dec.set_cn_rule(int(rule))
         dec.decode_batch_dev(d_llr.data_ptr(), F, iters, False, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
         nl, ms, fr = dec.last_decode_timing()
-        res.setdefault((rule, fpl, layout, skip), []).append(ms)
-for (rule, fpl, layout, skip), v in res.items():
+        res.setdefault((rule, fpl, layout, skip, eng), []).append(ms)
+for (rule, fpl, layout, skip, eng), v in res.items():
     best = min(v)
-    print("wps=%s skip=%s " % (layout, skip), end="")
+    print("engine=%-6s wps=%s skip=%s " % (eng, layout, skip), end="")
     print("rule=%-8s fpl=%s  ms=%s  best %.1f ms  %.0f GB/s  frac %.3f  %.3f Gbit/s" % (
         names[int(rule)], fpl, ["%.1f" % x for x in v], best, F * b_frame / best / 1e6, F * b_frame / best / 1e6 / 8000,
         F * (n - m) / best / 1e6))
