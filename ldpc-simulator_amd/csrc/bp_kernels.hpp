@@ -129,23 +129,33 @@ __device__ __forceinline__ float atanh2(float p) {
 // Math.signum: +-0 and NaN map to themselves (MinSumDecoder.java:84)
 __device__ __forceinline__ float signum(float x) { return (x > 0.0f) ? 1.0f : (x < 0.0f) ? -1.0f : x; }
 
-// phi(x) = -ln tanh(x/2) = 2 atanh(e^-x) for x >= 0, its own inverse.  The sum-product rule
-// 2 atanh(prod tanh(beta_k/2)) equals  sign * phi(sum phi(|beta_k|)), and in this form fp32 keeps
-// ~1e-6 relative accuracy over the whole range where the double-precision reference is
+// phi(x) = -ln tanh(x/2) = ln((1 + w)/(1 - w)), w = e^-x, for x >= 0; phi is its own inverse.
+// The sum-product rule 2 atanh(prod tanh(beta_k/2)) equals  sign * phi(sum phi(|beta_k|)), and in
+// this form fp32 stays accurate over the whole range in which the double-precision reference is
 // finite: 1 - tanh never has to be formed from a value rounded next to 1.
-//   x -> 0:  1 - e^-x from its Taylor polynomial (no cancellation), phi -> +Inf at 0;
-//   x large: w = e^-x small, 2 atanh(w) from its series (ln(1 + 2w) would cancel).
-// phi(+Inf) = 0, phi(NaN) = NaN.
-__device__ __forceinline__ float phi(float x) {
+// phi(0) = +Inf (2/0), phi(+Inf) = 0, phi(NaN) = NaN.
+//
+// Input side, x = |beta|.  For a confident message (w small) ln(1 + 2w + ...) would cancel, and the
+// sum S of such terms decides a large alpha, so there 2 atanh(w) comes from its series.  For a weak
+// message (x -> 0) 1 - w carries an absolute error of one ulp of 1; phi is then large and its error
+// only rescales an alpha that is already ~e^-phi, far below fp32 resolution of the posterior sums.
+__device__ __forceinline__ float phi_in(float x) {
     const float w = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    const float omw_poly =
-        x * fmaf(x, fmaf(x, fmaf(x, fmaf(x, fmaf(x, -1.0f / 720.0f, 1.0f / 120.0f), -1.0f / 24.0f), 1.0f / 6.0f), -0.5f), 1.0f);
-    const float omw = (x < 0.25f) ? omw_poly : (1.0f - w);
-    const float big = __builtin_amdgcn_logf((1.0f + w) * __builtin_amdgcn_rcpf(omw)) * 0.6931471805599453f;
+    const float big = __builtin_amdgcn_logf((1.0f + w) * __builtin_amdgcn_rcpf(1.0f - w)) * 0.6931471805599453f;
     const float w2 = w * w;
-    const float ser =
-        2.0f * w * fmaf(w2, fmaf(w2, fmaf(w2, fmaf(w2, 1.0f / 9.0f, 1.0f / 7.0f), 1.0f / 5.0f), 1.0f / 3.0f), 1.0f);
-    return (w < 0.15f) ? ser : big;
+    const float ser = (w + w) * fmaf(w2, fmaf(w2, 0.2f, 1.0f / 3.0f), 1.0f);  // w < 0.1: next term w^6/7 < 1.5e-7
+    return (w < 0.1f) ? ser : big;
+}
+
+// Output side, x = S = sum of input-side terms.  Small S means every other member is confident and
+// alpha = ln(2/S - ...) is large: 1 - e^-S must keep full relative accuracy, so below 1/8 it comes
+// from the Taylor polynomial.  Large S gives a small alpha whose absolute error (one ulp of 1 inside
+// the logarithm) is below the resolution of the sums it enters.
+__device__ __forceinline__ float phi_out(float x) {
+    const float w = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+    const float poly = x * fmaf(x, fmaf(x, fmaf(x, fmaf(x, 1.0f / 120.0f, -1.0f / 24.0f), 1.0f / 6.0f), -0.5f), 1.0f);
+    const float omw = (x < 0.125f) ? poly : (1.0f - w);  // x^5/720 < 5e-8 relative at 1/8
+    return __builtin_amdgcn_logf((1.0f + w) * __builtin_amdgcn_rcpf(omw)) * 0.6931471805599453f;
 }
 
 // |beta| above this has tanh(beta/2) == 1.0 in double (1 - tanh < 2^-54): the reference's
@@ -182,7 +192,8 @@ __device__ __forceinline__ void cn_compute1(float (&b)[D]) {
         for (int k = 0; k < D; ++k) {
             const float a = fabsf(b[k]);
             const uint32_t sg = __float_as_uint(b[k]) & 0x80000000u;
-            const float ph = (a > kDoubleTanhSaturation) ? 0.0f : phi(a);
+            // saturated input -> e^-inf = 0 -> phi = 0 exactly; a select on the argument keeps this straight-line
+            const float ph = phi_in((a > kDoubleTanhSaturation) ? __builtin_inff() : a);
             b[k] = __uint_as_float(__float_as_uint(ph) | sg);
             pre[k] = __uint_as_float(__float_as_uint(run) | rsg);
             run += ph;
@@ -194,7 +205,7 @@ __device__ __forceinline__ void cn_compute1(float (&b)[D]) {
         for (int k = D - 1; k >= 0; --k) {
             const float ph = fabsf(b[k]);
             const uint32_t sg = __float_as_uint(b[k]) & 0x80000000u;
-            const float mag = phi(fabsf(pre[k]) + suf);
+            const float mag = phi_out(fabsf(pre[k]) + suf);
             b[k] = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(pre[k]) & 0x80000000u) ^ ssg);
             suf += ph;
             ssg ^= sg;
@@ -288,7 +299,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
             float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
             const float a = fabsf(b);
             const uint32_t sg = __float_as_uint(b) & 0x80000000u;
-            const float ph = (a > kDoubleTanhSaturation) ? 0.0f : phi(a);
+            const float ph = phi_in((a > kDoubleTanhSaturation) ? __builtin_inff() : a);
             st[k * 64] = __uint_as_float(__float_as_uint(ph) | sg);
             sp[k * 64] = __uint_as_float(__float_as_uint(pre) | psg);
             pre += ph;
@@ -298,7 +309,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
         uint32_t ssg = 0u;
         for (int k = d - 1; k >= 0; --k) {
             const float sv = st[k * 64], pv = sp[k * 64];
-            const float mag = phi(fabsf(pv) + suf);
+            const float mag = phi_out(fabsf(pv) + suf);
             row[(long long)k * T] = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(pv) & 0x80000000u) ^ ssg);
             suf += fabsf(sv);
             ssg ^= __float_as_uint(sv) & 0x80000000u;

@@ -89,7 +89,7 @@ __device__ __forceinline__ int lds_syndrome(const LdsParams& p, const uint32_t* 
 
 template <int DC, int DV, int RULE, bool EARLY>
 __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
-    extern __shared__ float smem[];
+    extern __shared__ __align__(16) float smem[];
     float* msg = smem;                                   // [E]
     float* lam = smem + p.E;                             // [n]
     uint32_t* bits = reinterpret_cast<uint32_t*>(lam + p.n);  // [nw]
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
     if (t == 0) *red = 0;
     __syncthreads();
     // beta of the first iteration: lambda + the zero-initialised alpha (LogDecoder.java:57, :70-77)
-    for (long long e = t; e < p.E; e += nt) msg[e] = lam[p.edge_col[e]] + 0.0f;
+    for (int e = t; e < (int)p.E; e += nt) msg[e] = lam[p.edge_col[e]] + 0.0f;
     __syncthreads();
 
     int iters = p.max_iters, synd = 0;
@@ -131,9 +131,9 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
             const int i = t + c * nt;
             if (i < p.m) {
                 float x[DC];
-                lds_load_row<DC>(msg + (long long)i * DC, x);
+                lds_load_row<DC>(msg + i * DC, x);
                 cn_compute1<DC, RULE>(x);
-                lds_store_row<DC>(msg + (long long)i * DC, x);
+                lds_store_row<DC>(msg + i * DC, x);
             }
         }
         __syncthreads();
