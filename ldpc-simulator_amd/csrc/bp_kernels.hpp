@@ -129,38 +129,107 @@ __device__ __forceinline__ float atanh2(float p) {
 // Math.signum: +-0 and NaN map to themselves (MinSumDecoder.java:84)
 __device__ __forceinline__ float signum(float x) { return (x > 0.0f) ? 1.0f : (x < 0.0f) ? -1.0f : x; }
 
+// ---- the sum-product rule in the (sign, phi) domain ------------------------------------------
 // phi(x) = -ln tanh(x/2) = ln((1 + w)/(1 - w)), w = e^-x, for x >= 0; phi is its own inverse.
-// The sum-product rule 2 atanh(prod tanh(beta_k/2)) equals  sign * phi(sum phi(|beta_k|)), and in
-// this form fp32 stays accurate over the whole range in which the double-precision reference is
-// finite: 1 - tanh never has to be formed from a value rounded next to 1.
-// phi(0) = +Inf (2/0), phi(+Inf) = 0, phi(NaN) = NaN.
+// 2 atanh(prod tanh(beta_k/2)) equals  sign * phi(sum phi(|beta_k|)), and in this form fp32 stays
+// accurate over the whole range in which the double-precision reference is finite: 1 - tanh never
+// has to be formed from a value rounded next to 1.  phi(0) = +Inf (2/0), phi(+Inf) = 0, phi(NaN) = NaN.
 //
+// Everything below is written once for V = float and V = v2f (two independent checks per lane): on
+// gfx950 a plain fp32 VALU instruction and a packed one (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
+// cost the same issue cycles, so the packed form halves the cost of the polynomial and
+// bookkeeping arithmetic.  Both instantiate the same operations in the same order (fused
+// multiply-adds only where written), so they return identical bits per element.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float vexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ v2f vexp2(v2f x) { return v2f{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+__device__ __forceinline__ float vlog2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ v2f vlog2(v2f x) { return v2f{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)}; }
+__device__ __forceinline__ float vrcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ v2f vrcp(v2f x) { return v2f{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+__device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// (x < t) ? a : b, per element
+__device__ __forceinline__ float vsel_lt(float x, float t, float a, float b) { return (x < t) ? a : b; }
+__device__ __forceinline__ v2f vsel_lt(v2f x, float t, v2f a, v2f b) {
+    return v2f{(x.x < t) ? a.x : b.x, (x.y < t) ? a.y : b.y};
+}
+// (x > t) ? a : b, per element
+__device__ __forceinline__ float vsel_gt(float x, float t, float a, float b) { return (x > t) ? a : b; }
+__device__ __forceinline__ v2f vsel_gt(v2f x, float t, v2f a, v2f b) {
+    return v2f{(x.x > t) ? a.x : b.x, (x.y > t) ? a.y : b.y};
+}
+// +-1.0 carrying the sign bit of x (so that x * sign1(x) = |x| exactly, also for -0 and NaN)
+__device__ __forceinline__ float vsign1(float x) {
+    return __uint_as_float((__float_as_uint(x) & 0x80000000u) | 0x3f800000u);
+}
+__device__ __forceinline__ v2f vsign1(v2f x) { return v2f{vsign1(x.x), vsign1(x.y)}; }
+template <class V> __device__ __forceinline__ V vsplat(float x);
+template <> __device__ __forceinline__ float vsplat<float>(float x) { return x; }
+template <> __device__ __forceinline__ v2f vsplat<v2f>(float x) { return v2f{x, x}; }
+
 // Input side, x = |beta|.  For a confident message (w small) ln(1 + 2w + ...) would cancel, and the
 // sum S of such terms decides a large alpha, so there 2 atanh(w) comes from its series.  For a weak
 // message (x -> 0) 1 - w carries an absolute error of one ulp of 1; phi is then large and its error
 // only rescales an alpha that is already ~e^-phi, far below fp32 resolution of the posterior sums.
-__device__ __forceinline__ float phi_in(float x) {
-    const float w = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    const float big = __builtin_amdgcn_logf((1.0f + w) * __builtin_amdgcn_rcpf(1.0f - w)) * 0.6931471805599453f;
-    const float w2 = w * w;
-    const float ser = (w + w) * fmaf(w2, fmaf(w2, 0.2f, 1.0f / 3.0f), 1.0f);  // w < 0.1: next term w^6/7 < 1.5e-7
-    return (w < 0.1f) ? ser : big;
+template <class V>
+__device__ __forceinline__ V phi_in(V x) {
+#pragma clang fp contract(off)
+    const V one = vsplat<V>(1.0f);
+    const V w = vexp2(x * vsplat<V>(-1.4426950408889634f));
+    const V big = vlog2((one + w) * vrcp(one - w)) * vsplat<V>(0.6931471805599453f);
+    const V w2 = w * w;
+    const V ser = (w + w) * vfma(w2, vfma(w2, vsplat<V>(0.2f), vsplat<V>(1.0f / 3.0f)), one);  // next term w^6/7 < 1.5e-7
+    return vsel_lt(w, 0.1f, ser, big);
 }
 
 // Output side, x = S = sum of input-side terms.  Small S means every other member is confident and
 // alpha = ln(2/S - ...) is large: 1 - e^-S must keep full relative accuracy, so below 1/8 it comes
 // from the Taylor polynomial.  Large S gives a small alpha whose absolute error (one ulp of 1 inside
 // the logarithm) is below the resolution of the sums it enters.
-__device__ __forceinline__ float phi_out(float x) {
-    const float w = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    const float poly = x * fmaf(x, fmaf(x, fmaf(x, fmaf(x, 1.0f / 120.0f, -1.0f / 24.0f), 1.0f / 6.0f), -0.5f), 1.0f);
-    const float omw = (x < 0.125f) ? poly : (1.0f - w);  // x^5/720 < 5e-8 relative at 1/8
-    return __builtin_amdgcn_logf((1.0f + w) * __builtin_amdgcn_rcpf(omw)) * 0.6931471805599453f;
+template <class V>
+__device__ __forceinline__ V phi_out(V x) {
+#pragma clang fp contract(off)
+    const V one = vsplat<V>(1.0f);
+    const V w = vexp2(x * vsplat<V>(-1.4426950408889634f));
+    const V poly = x * vfma(x, vfma(x, vfma(x, vfma(x, vsplat<V>(1.0f / 120.0f), vsplat<V>(-1.0f / 24.0f)),
+                                            vsplat<V>(1.0f / 6.0f)), vsplat<V>(-0.5f)), one);
+    const V omw = vsel_lt(x, 0.125f, poly, one - w);  // x^5/720 < 5e-8 relative at 1/8
+    return vlog2((one + w) * vrcp(omw)) * vsplat<V>(0.6931471805599453f);
 }
 
 // |beta| above this has tanh(beta/2) == 1.0 in double (1 - tanh < 2^-54): the reference's
 // factor is exactly 1 there, so its log-domain term is exactly 0.
 constexpr float kDoubleTanhSaturation = 38.1230949f;  // 55 ln 2
+
+// beta[0..D) -> alpha[0..D) in place.  Sums ascend over k like the products of LogDecoder.java:86-91
+// they stand for; leave-one-out is (prefix of k) + (suffix of k), signs likewise by products of +-1.
+template <class V, int D>
+__device__ __forceinline__ void cn_logtanh(V (&b)[D]) {
+#pragma clang fp contract(off)
+    V ph[D], sg[D], pre[D], psg[D];
+    V run = vsplat<V>(0.0f), rs = vsplat<V>(1.0f);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        sg[k] = vsign1(b[k]);
+        const V a = b[k] * sg[k];
+        // saturated input -> e^-inf = 0 -> phi = 0 exactly (a select on the argument: no branch)
+        ph[k] = phi_in<V>(vsel_gt(a, kDoubleTanhSaturation, vsplat<V>(__builtin_inff()), a));
+        pre[k] = run;
+        psg[k] = rs;
+        run = run + ph[k];
+        rs = rs * sg[k];
+    }
+    V suf = vsplat<V>(0.0f), ss = vsplat<V>(1.0f);
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        const V mag = phi_out<V>(pre[k] + suf);
+        b[k] = mag * (psg[k] * ss);
+        suf = suf + ph[k];
+        ss = ss * sg[k];
+    }
+}
 
 // beta[0..D) -> alpha[0..D) in place, D a compile-time degree.  The FPL frames of a lane are
 // independent; they are processed one after the other so that only one frame's prefix array is live.
@@ -183,33 +252,7 @@ __device__ __forceinline__ void cn_compute1(float (&b)[D]) {
             b[k] = atanh2(p);
         }
     } else if constexpr (RULE == kCnLogTanh) {
-        // same rule in the (sign, phi) domain; sums ascend like the products they stand for.
-        // phi >= 0 and its prefix sums >= 0, so their sign bits carry sign(beta) and its prefix product.
-        float pre[D];
-        float run = 0.0f;
-        uint32_t rsg = 0u;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const float a = fabsf(b[k]);
-            const uint32_t sg = __float_as_uint(b[k]) & 0x80000000u;
-            // saturated input -> e^-inf = 0 -> phi = 0 exactly; a select on the argument keeps this straight-line
-            const float ph = phi_in((a > kDoubleTanhSaturation) ? __builtin_inff() : a);
-            b[k] = __uint_as_float(__float_as_uint(ph) | sg);
-            pre[k] = __uint_as_float(__float_as_uint(run) | rsg);
-            run += ph;
-            rsg ^= sg;
-        }
-        float suf = 0.0f;
-        uint32_t ssg = 0u;
-#pragma unroll
-        for (int k = D - 1; k >= 0; --k) {
-            const float ph = fabsf(b[k]);
-            const uint32_t sg = __float_as_uint(b[k]) & 0x80000000u;
-            const float mag = phi_out(fabsf(pre[k]) + suf);
-            b[k] = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(pre[k]) & 0x80000000u) ^ ssg);
-            suf += ph;
-            ssg ^= sg;
-        }
+        cn_logtanh<float, D>(b);
     } else {
         // MinSumDecoder.java:79-93: alpha = prod signum(beta) * min|beta| * 0.7 over k != j;
         // "minbata > |beta|" never selects a NaN, and Double.MAX_VALUE becomes FLT_MAX.
@@ -299,7 +342,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
             float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
             const float a = fabsf(b);
             const uint32_t sg = __float_as_uint(b) & 0x80000000u;
-            const float ph = phi_in((a > kDoubleTanhSaturation) ? __builtin_inff() : a);
+            const float ph = phi_in<float>((a > kDoubleTanhSaturation) ? __builtin_inff() : a);
             st[k * 64] = __uint_as_float(__float_as_uint(ph) | sg);
             sp[k * 64] = __uint_as_float(__float_as_uint(pre) | psg);
             pre += ph;
@@ -309,7 +352,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
         uint32_t ssg = 0u;
         for (int k = d - 1; k >= 0; --k) {
             const float sv = st[k * 64], pv = sp[k * 64];
-            const float mag = phi_out(fabsf(pv) + suf);
+            const float mag = phi_out<float>(fabsf(pv) + suf);
             row[(long long)k * T] = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(pv) & 0x80000000u) ^ ssg);
             suf += fabsf(sv);
             ssg ^= __float_as_uint(sv) & 0x80000000u;

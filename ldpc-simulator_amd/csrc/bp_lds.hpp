@@ -20,8 +20,7 @@
 
 namespace ldpc {
 
-constexpr int kLdsMaxCpt = 4;  // checks per thread
-constexpr int kLdsMaxVpt = 8;  // variables per thread
+constexpr int kLdsVpt = 8;  // variables per thread; threads per frame = n / 8, checks per thread = 8 m / n
 
 struct LdsParams {
     int m, n, nw;
@@ -87,7 +86,8 @@ __device__ __forceinline__ int lds_syndrome(const LdsParams& p, const uint32_t* 
     return total;
 }
 
-template <int DC, int DV, int RULE, bool EARLY>
+// CPT checks and kLdsVpt variables per thread, exactly: m = CPT * blockDim.x, n = kLdsVpt * blockDim.x.
+template <int DC, int DV, int RULE, bool EARLY, int CPT>
 __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
     extern __shared__ __align__(16) float smem[];
     float* msg = smem;                                   // [E]
@@ -99,12 +99,12 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
     if (frame >= p.frames) return;
 
     // this thread's variables and their edge slots (byte-free element offsets into msg)
-    int off[kLdsMaxVpt][DV];
+    int off[kLdsVpt][DV];
 #pragma unroll
-    for (int v = 0; v < kLdsMaxVpt; ++v) {
+    for (int v = 0; v < kLdsVpt; ++v) {
         const int j = t + v * nt;
 #pragma unroll
-        for (int k = 0; k < DV; ++k) off[v][k] = (j < p.n) ? p.col_edge[(long long)j * DV + k] : 0;
+        for (int k = 0; k < DV; ++k) off[v][k] = p.col_edge[(long long)j * DV + k];
     }
     // channel LLRs of the frame -> LDS
     if (p.llr) {
@@ -126,38 +126,54 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
     int iters = p.max_iters, synd = 0;
     for (int it = 0; it < p.max_iters; ++it) {
         // check nodes: beta -> alpha in place
+        if constexpr (RULE == kCnLogTanh && CPT % 2 == 0) {
+            // two checks per step in the two halves of packed fp32 registers
 #pragma unroll
-        for (int c = 0; c < kLdsMaxCpt; ++c) {
-            const int i = t + c * nt;
-            if (i < p.m) {
+            for (int c = 0; c < CPT; c += 2) {
+                float* r0 = msg + (t + c * nt) * DC;
+                float* r1 = msg + (t + (c + 1) * nt) * DC;
+                float x0[DC], x1[DC];
+                lds_load_row<DC>(r0, x0);
+                lds_load_row<DC>(r1, x1);
+                v2f x[DC];
+#pragma unroll
+                for (int k = 0; k < DC; ++k) x[k] = v2f{x0[k], x1[k]};
+                cn_logtanh<v2f, DC>(x);
+#pragma unroll
+                for (int k = 0; k < DC; ++k) { x0[k] = x[k].x; x1[k] = x[k].y; }
+                lds_store_row<DC>(r0, x0);
+                lds_store_row<DC>(r1, x1);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                float* r0 = msg + (t + c * nt) * DC;
                 float x[DC];
-                lds_load_row<DC>(msg + i * DC, x);
+                lds_load_row<DC>(r0, x);
                 cn_compute1<DC, RULE>(x);
-                lds_store_row<DC>(msg + i * DC, x);
+                lds_store_row<DC>(r0, x);
             }
         }
         __syncthreads();
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit
         const bool write_beta = EARLY || (it + 1 < p.max_iters);
 #pragma unroll
-        for (int v = 0; v < kLdsMaxVpt; ++v) {
+        for (int v = 0; v < kLdsVpt; ++v) {
             const int j = t + v * nt;
-            if (j < p.n) {
-                float a[DV][1], l[1], g[1];
+            float a[DV][1], l[1], g[1];
 #pragma unroll
-                for (int k = 0; k < DV; ++k) a[k][0] = msg[off[v][k]];
-                l[0] = lam[j];
-                vn_compute<1, DV>(a, l, g);
-                if (write_beta) {
+            for (int k = 0; k < DV; ++k) a[k][0] = msg[off[v][k]];
+            l[0] = lam[j];
+            vn_compute<1, DV>(a, l, g);
+            if (write_beta) {
 #pragma unroll
-                    for (int k = 0; k < DV; ++k) msg[off[v][k]] = a[k][0];
-                }
-                if (EARLY || it + 1 == p.max_iters) {
-                    const unsigned long long mask = __ballot(g[0] < 0.0f);  // "(gamma[j] < 0) ? 1 : 0", :104
-                    if ((t & 63) == 0) {
-                        bits[j >> 5] = (uint32_t)mask;
-                        if (((j >> 5) + 1) < p.nw) bits[(j >> 5) + 1] = (uint32_t)(mask >> 32);
-                    }
+                for (int k = 0; k < DV; ++k) msg[off[v][k]] = a[k][0];
+            }
+            if (EARLY || it + 1 == p.max_iters) {
+                const unsigned long long mask = __ballot(g[0] < 0.0f);  // "(gamma[j] < 0) ? 1 : 0", :104
+                if ((t & 63) == 0) {  // j is a multiple of 64 here and n a multiple of 64
+                    bits[j >> 5] = (uint32_t)mask;
+                    bits[(j >> 5) + 1] = (uint32_t)(mask >> 32);
                 }
             }
         }
@@ -196,12 +212,12 @@ struct LdsLaunch {
     hipStream_t stream;
 };
 
-template <int DC, int DV>
+template <int DC, int DV, int CPT>
 inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
     const dim3 grid((unsigned)p.frames), block((unsigned)l.threads);
 #define LDPC_LDS(R, E)                                                                                       \
     do {                                                                                                     \
-        auto k = bp_lds_kernel<DC, DV, R, E>;                                                                \
+        auto k = bp_lds_kernel<DC, DV, R, E, CPT>;                                                                \
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                            (int)l.lds_bytes);                                                \
         if (e != hipSuccess) return e;                                                                       \

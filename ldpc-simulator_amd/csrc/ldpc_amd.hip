@@ -190,10 +190,10 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     // Frame-resident engine: regular code whose messages + LLRs fit twice into a CU's LDS.
     {
         const bool shape = (c->reg_dc == 6 && c->reg_dv == 3) || (c->reg_dc == 8 && c->reg_dv == 2);
-        int nt = ((n + kLdsMaxVpt - 1) / kLdsMaxVpt + 63) / 64 * 64;
+        // exact tiling: 8 variables and 8 m / n checks per thread, whole wavefronts
+        const int nt = n / kLdsVpt;
         const size_t lds_bytes = ((size_t)c->E + (size_t)n + (size_t)c->nw + 4) * sizeof(float);
-        bool use = shape && nt <= 512 && (long long)kLdsMaxCpt * nt >= c->m && lds_bytes <= 80 * 1024 &&
-                   frames <= 0x7fffffffll;
+        bool use = shape && n % (kLdsVpt * 64) == 0 && nt <= 512 && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll;
         if (const char* env = getenv("LDPC_AMD_ENGINE")) {
             if (!strcmp(env, "stream")) use = false;
         }
