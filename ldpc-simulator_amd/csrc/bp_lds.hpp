@@ -38,6 +38,20 @@ struct LdsParams {
     int32_t* out_synd;     // [frames] or null
 };
 
+// LDS slot of CSR edge e = (check i, position k).  With PAIR the rows of the two checks a thread
+// processes together (i = t + c*nt for c = 2q, 2q+1) are interleaved element by element, so that
+// (check 2q position k, check 2q+1 position k) is one aligned 8-byte pair = one packed register.
+template <int DC, bool PAIR>
+__device__ __forceinline__ int lds_slot(int e, int nt) {
+    if constexpr (!PAIR) {
+        return e;
+    } else {
+        const int i = e / DC, k = e - i * DC;
+        const int c = i / nt, t = i - c * nt;
+        return 2 * DC * (t + (c >> 1) * nt) + 2 * k + (c & 1);
+    }
+}
+
 template <int DC>
 __device__ __forceinline__ void lds_load_row(const float* p, float (&x)[DC]) {
     if constexpr (DC % 2 == 0) {
@@ -97,14 +111,16 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
     const int t = threadIdx.x, nt = blockDim.x;
     const long long frame = blockIdx.x;
     if (frame >= p.frames) return;
+    constexpr bool PAIR = (RULE == kCnLogTanh) && (CPT % 2 == 0);
+    char* msgb = reinterpret_cast<char*>(msg);
 
-    // this thread's variables and their edge slots (byte-free element offsets into msg)
+    // this thread's variables and the byte offsets of their edge slots in msg
     int off[kLdsVpt][DV];
 #pragma unroll
     for (int v = 0; v < kLdsVpt; ++v) {
         const int j = t + v * nt;
 #pragma unroll
-        for (int k = 0; k < DV; ++k) off[v][k] = p.col_edge[(long long)j * DV + k];
+        for (int k = 0; k < DV; ++k) off[v][k] = 4 * lds_slot<DC, PAIR>(p.col_edge[(long long)j * DV + k], nt);
     }
     // channel LLRs of the frame -> LDS
     if (p.llr) {
@@ -120,29 +136,28 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
     if (t == 0) *red = 0;
     __syncthreads();
     // beta of the first iteration: lambda + the zero-initialised alpha (LogDecoder.java:57, :70-77)
-    for (int e = t; e < (int)p.E; e += nt) msg[e] = lam[p.edge_col[e]] + 0.0f;
+    for (int e = t; e < (int)p.E; e += nt) msg[lds_slot<DC, PAIR>(e, nt)] = lam[p.edge_col[e]] + 0.0f;
     __syncthreads();
 
     int iters = p.max_iters, synd = 0;
     for (int it = 0; it < p.max_iters; ++it) {
         // check nodes: beta -> alpha in place
-        if constexpr (RULE == kCnLogTanh && CPT % 2 == 0) {
+        if constexpr (PAIR) {
             // two checks per step in the two halves of packed fp32 registers
+            // (all rows are read before any is written back: distinct checks never share a slot)
+            v2f x[CPT / 2][DC];
 #pragma unroll
-            for (int c = 0; c < CPT; c += 2) {
-                float* r0 = msg + (t + c * nt) * DC;
-                float* r1 = msg + (t + (c + 1) * nt) * DC;
-                float x0[DC], x1[DC];
-                lds_load_row<DC>(r0, x0);
-                lds_load_row<DC>(r1, x1);
-                v2f x[DC];
+            for (int q = 0; q < CPT / 2; ++q) {
+                const v2f* row = reinterpret_cast<const v2f*>(msg + 2 * DC * (t + q * nt));
 #pragma unroll
-                for (int k = 0; k < DC; ++k) x[k] = v2f{x0[k], x1[k]};
-                cn_logtanh<v2f, DC>(x);
+                for (int k = 0; k < DC; ++k) x[q][k] = row[k];
+            }
 #pragma unroll
-                for (int k = 0; k < DC; ++k) { x0[k] = x[k].x; x1[k] = x[k].y; }
-                lds_store_row<DC>(r0, x0);
-                lds_store_row<DC>(r1, x1);
+            for (int q = 0; q < CPT / 2; ++q) {
+                v2f* row = reinterpret_cast<v2f*>(msg + 2 * DC * (t + q * nt));
+                cn_logtanh<v2f, DC>(x[q]);
+#pragma unroll
+                for (int k = 0; k < DC; ++k) row[k] = x[q][k];
             }
         } else {
 #pragma unroll
@@ -157,17 +172,24 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
         __syncthreads();
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit
         const bool write_beta = EARLY || (it + 1 < p.max_iters);
+        // (all gathers are issued before any scatter: distinct variables never share a slot)
+        float va[kLdsVpt][DV][1], vl[kLdsVpt][1];
+#pragma unroll
+        for (int v = 0; v < kLdsVpt; ++v) {
+#pragma unroll
+            for (int k = 0; k < DV; ++k) va[v][k][0] = *reinterpret_cast<const float*>(msgb + off[v][k]);
+            vl[v][0] = lam[t + v * nt];
+        }
 #pragma unroll
         for (int v = 0; v < kLdsVpt; ++v) {
             const int j = t + v * nt;
-            float a[DV][1], l[1], g[1];
-#pragma unroll
-            for (int k = 0; k < DV; ++k) a[k][0] = msg[off[v][k]];
-            l[0] = lam[j];
+            float (&a)[DV][1] = va[v];
+            float (&l)[1] = vl[v];
+            float g[1];
             vn_compute<1, DV>(a, l, g);
             if (write_beta) {
 #pragma unroll
-                for (int k = 0; k < DV; ++k) msg[off[v][k]] = a[k][0];
+                for (int k = 0; k < DV; ++k) *reinterpret_cast<float*>(msgb + off[v][k]) = a[k][0];
             }
             if (EARLY || it + 1 == p.max_iters) {
                 const unsigned long long mask = __ballot(g[0] < 0.0f);  // "(gamma[j] < 0) ? 1 : 0", :104
