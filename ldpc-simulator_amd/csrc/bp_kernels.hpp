@@ -169,39 +169,51 @@ template <class V> __device__ __forceinline__ V vsplat(float x);
 template <> __device__ __forceinline__ float vsplat<float>(float x) { return x; }
 template <> __device__ __forceinline__ v2f vsplat<v2f>(float x) { return v2f{x, x}; }
 
-// Input side, x = |beta|.  For a confident message (w small) ln(1 + 2w + ...) would cancel, and the
-// sum S of such terms decides a large alpha, so there 2 atanh(w) comes from its series.  For a weak
-// message (x -> 0) 1 - w carries an absolute error of one ulp of 1; phi is then large and its error
-// only rescales an alpha that is already ~e^-phi, far below fp32 resolution of the posterior sums.
+// Units: with this rule every LLR and message is held in BITS (natural-log value / ln 2; the layout
+// kernels scale the channel LLRs once on the way in, decisions only need signs).  Then
+// w = 2^-x is the bare hardware exp2 and phi comes straight out of the hardware log2: the four
+// multiplications by ln 2 / log2 e per edge disappear, and the constants of the two series absorb
+// the factor.  Below, x, S and phi are all in bits.
+//
+// Input side, x = |beta|.  For a confident message (w small) log2(1 + 2w + ...) would cancel, and the
+// sum S of such terms decides a large alpha, so there 2 atanh(w) / ln 2 comes from its series.  For a
+// weak message (x -> 0) 1 - w carries an absolute error of one ulp of 1; phi is then large and its
+// error only rescales an alpha that is already ~2^-phi, far below fp32 resolution of the posterior sums.
 template <class V>
 __device__ __forceinline__ V phi_in(V x) {
 #pragma clang fp contract(off)
     const V one = vsplat<V>(1.0f);
-    const V w = vexp2(x * vsplat<V>(-1.4426950408889634f));
-    const V big = vlog2((one + w) * vrcp(one - w)) * vsplat<V>(0.6931471805599453f);
+    const V w = vexp2(-x);
+    const V big = vlog2((one + w) * vrcp(one - w));
     const V w2 = w * w;
-    const V ser = (w + w) * vfma(w2, vfma(w2, vsplat<V>(0.2f), vsplat<V>(1.0f / 3.0f)), one);  // next term w^6/7 < 1.5e-7
+    // (2 / ln 2) (w + w^3/3 + w^5/5); w < 0.1: next term w^6/7 < 1.5e-7 relative
+    const V ser = w * vfma(w2, vfma(w2, vsplat<V>(0.5770780163555854f), vsplat<V>(0.9617966939259756f)),
+                           vsplat<V>(2.8853900817779268f));
     return vsel_lt(w, 0.1f, ser, big);
 }
 
 // Output side, x = S = sum of input-side terms.  Small S means every other member is confident and
-// alpha = ln(2/S - ...) is large: 1 - e^-S must keep full relative accuracy, so below 1/8 it comes
-// from the Taylor polynomial.  Large S gives a small alpha whose absolute error (one ulp of 1 inside
-// the logarithm) is below the resolution of the sums it enters.
+// alpha = log2(2/(S ln 2) - ...) is large: 1 - 2^-S must keep full relative accuracy, so below
+// S ln 2 = 1/8 it comes from the Taylor polynomial of 1 - e^-y, y = S ln 2.  Large S gives a small
+// alpha whose absolute error (one ulp of 1 inside the logarithm) is below the resolution of the sums
+// it enters.
 template <class V>
 __device__ __forceinline__ V phi_out(V x) {
 #pragma clang fp contract(off)
     const V one = vsplat<V>(1.0f);
-    const V w = vexp2(x * vsplat<V>(-1.4426950408889634f));
-    const V poly = x * vfma(x, vfma(x, vfma(x, vfma(x, vsplat<V>(1.0f / 120.0f), vsplat<V>(-1.0f / 24.0f)),
-                                            vsplat<V>(1.0f / 6.0f)), vsplat<V>(-0.5f)), one);
-    const V omw = vsel_lt(x, 0.125f, poly, one - w);  // x^5/720 < 5e-8 relative at 1/8
-    return vlog2((one + w) * vrcp(omw)) * vsplat<V>(0.6931471805599453f);
+    const V w = vexp2(-x);
+    // x (L - L^2 x/2 + L^3 x^2/6 - L^4 x^3/24 + L^5 x^4/120), L = ln 2; next term < 5e-8 relative at y = 1/8
+    const V poly = x * vfma(x, vfma(x, vfma(x, vfma(x, vsplat<V>(1.3333558146428443e-3f), vsplat<V>(-9.618129107628477e-3f)),
+                                            vsplat<V>(5.550410866482158e-2f)), vsplat<V>(-0.2402265069591007f)),
+                            vsplat<V>(0.6931471805599453f));
+    const V omw = vsel_lt(x, 0.18033688011112042f, poly, one - w);
+    return vlog2((one + w) * vrcp(omw));
 }
 
-// |beta| above this has tanh(beta/2) == 1.0 in double (1 - tanh < 2^-54): the reference's
-// factor is exactly 1 there, so its log-domain term is exactly 0.
-constexpr float kDoubleTanhSaturation = 38.1230949f;  // 55 ln 2
+// |beta| above 55 ln 2 nats = 55 bits has tanh(beta/2) == 1.0 in double (1 - tanh < 2^-54): the
+// reference's factor is exactly 1 there, so its log-domain term is exactly 0.
+constexpr float kDoubleTanhSaturation = 55.0f;   // bits
+constexpr float kBitsPerNat = 1.4426950408889634f;  // 1 / ln 2: scale of the channel LLRs for this rule
 
 // beta[0..D) -> alpha[0..D) in place.  Sums ascend over k like the products of LogDecoder.java:86-91
 // they stand for; leave-one-out is (prefix of k) + (suffix of k), signs likewise by products of +-1.

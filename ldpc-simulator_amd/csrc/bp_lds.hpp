@@ -29,7 +29,8 @@ struct LdsParams {
     const int* col_edge;   // [E]
     const float* llr;      // [frames][n] channel LLRs, or null
     const uint8_t* r;      // [frames][n] hard received words (then lambda = +-l0 / +-l1), or null
-    float l0, l1;
+    float l0, l1;          // already in the rule's LLR unit
+    float scale;           // channel LLR unit conversion (see FloatLlr)
     int g_length;          // n - m
     long long frames;
     int max_iters;
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
     // channel LLRs of the frame -> LDS
     if (p.llr) {
         const float* src = p.llr + frame * p.n;
-        for (int j = t; j < p.n; j += nt) lam[j] = src[j];
+        for (int j = t; j < p.n; j += nt) lam[j] = src[j] * p.scale;
     } else {
         const uint8_t* src = p.r + frame * p.n;
         for (int j = t; j < p.n; j += nt) {

@@ -11,9 +11,12 @@ namespace ldpc {
 // in[frame][j] (row per frame, what a caller holds) becomes lam[tile][j][t], t = frame % T:
 // the layout in which lane t of a wave reads its own frame with one coalesced row per j.
 // A 64 x 64 block goes through LDS (row stride 65 words, conflict-free both ways).
+// `scale` converts the caller's natural-log LLRs into the unit the check-node rule works in
+// (1/ln 2 for the log-tanh rule, 1 otherwise); decisions depend on signs only.
 struct FloatLlr {
     const float* in;
-    __device__ float operator()(long long idx, int /*j*/) const { return in[idx]; }
+    float scale;
+    __device__ float operator()(long long idx, int /*j*/) const { return in[idx] * scale; }
 };
 // lambda from a hard received word: LogDecoder.java:45-54 / LogDecoderBefore.java:45-50
 struct BscLlr {

@@ -149,8 +149,13 @@ struct SrcArgs {
     Src kind;
     const float* llr;
     const uint8_t* r;
-    float l0, l1;
+    double l0, l1;  // BSC magnitudes in nats, double as the reference forms them
 };
+
+// LLR unit of the selected check-node rule (see bp_kernels.hpp): bits for log-tanh, nats otherwise.
+double llr_scale(const ldpc_amd_ctx* c) {
+    return (c->cn_rule == LDPC_AMD_CN_MINSUM || c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH) ? 1.0 : 1.4426950408889634;
+}
 
 int launch_bp(ldpc_amd_ctx* c, const BpParams& p, int fpl, bool early, int wpb, size_t lds_bytes, bool pipelined,
               hipStream_t s) {
@@ -203,7 +208,8 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             q.edge_col = c->d_edge_col; q.col_edge = c->d_col_edge;
             q.llr = src.kind == Src::Float ? src.llr : nullptr;
             q.r = src.kind == Src::Bsc ? src.r : nullptr;
-            q.l0 = src.l0; q.l1 = src.l1; q.g_length = n - c->m;
+            q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
+            q.scale = (float)llr_scale(c);
             q.frames = frames; q.max_iters = max_iters;
             q.hard = d_hard; q.out_iters = d_iters; q.out_synd = d_synd;
             LdsLaunch l;
@@ -300,11 +306,11 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         {
             const dim3 grid((unsigned)(tiles * (T / 64)), (unsigned)((n + 63) / 64)), block(256);
             if (src.kind == Src::Float) {
-                hipLaunchKernelGGL((load_lambda_kernel<FloatLlr>), grid, block, 0, s, FloatLlr{src.llr}, ws_lam,
+                hipLaunchKernelGGL((load_lambda_kernel<FloatLlr>), grid, block, 0, s, FloatLlr{src.llr, (float)llr_scale(c)}, ws_lam,
                                    p.lam_tile, p.lam_row, n, T, frame_base, frames);
             } else {
                 hipLaunchKernelGGL((load_lambda_kernel<BscLlr>), grid, block, 0, s,
-                                   BscLlr{src.r, src.l0, src.l1, n - c->m}, ws_lam, p.lam_tile, p.lam_row, n, T,
+                                   BscLlr{src.r, (float)(src.l0 * llr_scale(c)), (float)(src.l1 * llr_scale(c)), n - c->m}, ws_lam, p.lam_tile, p.lam_row, n, T,
                                    frame_base, frames);
             }
             LDPC_HIP(c, hipGetLastError());
@@ -329,15 +335,15 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     return LDPC_AMD_OK;
 }
 
-int bsc_magnitudes(ldpc_amd_ctx* c, double e, int llr_mode, float* l0, float* l1) {
+int bsc_magnitudes(ldpc_amd_ctx* c, double e, int llr_mode, double* l0, double* l1) {
     if (!(e > 0.0) || !(e < 1.0)) return fail(c, LDPC_AMD_EINVAL, "crossover probability must be in (0,1)");
     const double d0 = std::log((1 - e) / e);  // LogDecoder.java:46
     double d1 = d0;
     if (llr_mode == LDPC_AMD_LLR_PARITY_LN1E20) d1 = std::log((1 - 0.00000000000000000001) / 0.00000000000000000001);
     else if (llr_mode == LDPC_AMD_LLR_PARITY_1EM7) d1 = std::log((1 - 0.0000001) / 0.0000001);
     else if (llr_mode != LDPC_AMD_LLR_UNIFORM) return fail(c, LDPC_AMD_EINVAL, "unknown llr_mode");
-    *l0 = (float)d0;
-    *l1 = (float)d1;
+    *l0 = d0;
+    *l1 = d1;
     return LDPC_AMD_OK;
 }
 
@@ -503,7 +509,7 @@ int ldpc_amd_decode_batch_dev(ldpc_amd_ctx* c, const float* d_llr, int64_t frame
     if (!d_llr && frames > 0) return fail(c, LDPC_AMD_EINVAL, "decode_batch: llr is null");
     DeviceGuard guard(c->device);
     if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
-    SrcArgs src{Src::Float, d_llr, nullptr, 0.f, 0.f};
+    SrcArgs src{Src::Float, d_llr, nullptr, 0.0, 0.0};
     return decode_dev(c, src, frames, max_iters, early_term, d_hard, d_iters, d_synd, (hipStream_t)stream);
 }
 
@@ -512,7 +518,7 @@ int ldpc_amd_decode_bsc_batch_dev(ldpc_amd_ctx* c, const uint8_t* d_r, int64_t f
                                   int32_t* d_synd, void* stream) {
     if (!c) return LDPC_AMD_EINVAL;
     if (!d_r && frames > 0) return fail(c, LDPC_AMD_EINVAL, "decode_bsc_batch: r is null");
-    float l0, l1;
+    double l0, l1;
     if (int rc = bsc_magnitudes(c, e, llr_mode, &l0, &l1)) return rc;
     DeviceGuard guard(c->device);
     if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
@@ -526,7 +532,7 @@ static int decode_host(ldpc_amd_ctx* c, const void* in, size_t in_elem, bool bsc
                        int32_t* synd) {
     if (!c) return LDPC_AMD_EINVAL;
     if (frames < 0 || (frames > 0 && (!in || !hard))) return fail(c, LDPC_AMD_EINVAL, "decode: null buffer");
-    float l0 = 0.f, l1 = 0.f;
+    double l0 = 0.0, l1 = 0.0;
     if (bsc)
         if (int rc = bsc_magnitudes(c, e, llr_mode, &l0, &l1)) return rc;
     DeviceGuard guard(c->device);
@@ -614,7 +620,7 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
         c->counters_len = nc;
     }
     LDPC_HIP(c, hipMemset(c->d_counters, 0, nc * sizeof(unsigned long long)));
-    float l0 = 0.f, l1 = 0.f;
+    double l0 = 0.0, l1 = 0.0;
     const bool awgn = channel == LDPC_AMD_CH_AWGN;
     if (!awgn) {
         const int mode = (channel == LDPC_AMD_CH_BSC_INFO) ? LDPC_AMD_LLR_PARITY_LN1E20 : LDPC_AMD_LLR_UNIFORM;
@@ -634,7 +640,7 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
         SrcArgs src{};
         if (awgn) {
             rc = gen_awgn(c, param, seed, first_frame + f0, nf, (float*)c->stage[0], nullptr);
-            src = SrcArgs{Src::Float, (const float*)c->stage[0], nullptr, 0.f, 0.f};
+            src = SrcArgs{Src::Float, (const float*)c->stage[0], nullptr, 0.0, 0.0};
         } else {
             rc = gen_bsc(c, channel, param, seed, first_frame + f0, nf, (uint8_t*)c->stage[0], nullptr);
             src = SrcArgs{Src::Bsc, nullptr, (const uint8_t*)c->stage[0], l0, l1};
