@@ -44,7 +44,7 @@ def cpu_baseline(code, ebn0_db, iters, budget_s):
     except AttributeError:
         cores = os.cpu_count() or 1
     threads = max(1, min(cores, oc.max_threads(), 16))
-    probe = 2 * threads
+    probe = 8 * threads
     llr = oc.gen_awgn_llr(m, n, ebn0_db, 0x5EED, 0, probe)
     t0 = time.perf_counter()
     g.decode_llr_batch(llr, iters, False, threads=threads)
@@ -157,6 +157,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    kernel = dec.last_decode_kernel()
     cnt = d_cnt.cpu().numpy()
     k = n - m
     total_frames = F * world * args.steps
@@ -192,8 +193,12 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": measured_traffic("bp_decode_kernel", F, iters, n),
-            "kernel": "bp_decode_kernel",
+            "traffic": measured_traffic(kernel, F, iters, n),
+            "kernel": kernel,
+            "note": ("frame-resident kernel: messages stay in LDS, so `achieved` (algorithmic message bytes / time) "
+                     "exceeds what HBM could deliver and `traffic` (measured HBM bytes) is far below it; the kernel is "
+                     "bound by VALU issue, see DESIGN.md" if kernel == "bp_lds_kernel" else
+                     "frame-major streaming kernel: HBM-bound"),
             "launch_ms": launch_s * 1e3,
             "algorithmic_bytes_per_launch": frames_per_launch * b_frame,
         },

@@ -183,6 +183,14 @@ int ldpc_amd_simulate(ldpc_amd_ctx* ctx, int32_t channel, double param, uint64_t
  */
 int ldpc_amd_last_decode_timing(ldpc_amd_ctx* ctx, int32_t* launches, double* kernel_ms, int64_t* frames);
 
+/*
+ * Name of the message-passing kernel the most recent decode ran: "bp_lds_kernel" (frame-resident:
+ * a regular code whose messages fit in LDS; one workgroup per frame, messages never leave the CU) or
+ * "bp_decode_kernel" (frame-major streaming through HBM: any code).  The environment variable
+ * LDPC_AMD_ENGINE=stream forces the second.  Both return identical bits.
+ */
+const char* ldpc_amd_last_decode_kernel(const ldpc_amd_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

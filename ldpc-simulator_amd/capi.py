@@ -43,6 +43,7 @@ SIGNATURES = {
     "ldpc_amd_count_errors_dev": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "ldpc_amd_simulate": (C.c_int, [_vp, _i32, _f64, _u64, _i64, _i64, _i32, _i32, _vp]),
     "ldpc_amd_last_decode_timing": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "ldpc_amd_last_decode_kernel": (C.c_char_p, [_vp]),
 }
 
 _lib = None
@@ -212,6 +213,9 @@ class Decoder:
     def count_errors_dev(self, frames, d_hard, d_rx_hard, d_iters, d_synd, max_iters, d_counters, stream=0):
         self._check(self._lib.ldpc_amd_count_errors_dev(self._h, int(frames), d_hard, d_rx_hard or None, d_iters,
                                                         d_synd, int(max_iters), d_counters, stream or None))
+
+    def last_decode_kernel(self):
+        return (self._lib.ldpc_amd_last_decode_kernel(self._h) or b"").decode()
 
     def last_decode_timing(self):
         n, ms, fr = C.c_int32(), C.c_double(), C.c_int64()

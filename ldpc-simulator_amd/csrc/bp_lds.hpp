@@ -25,8 +25,12 @@ constexpr int kLdsVpt = 8;  // variables per thread; threads per frame = n / 8, 
 struct LdsParams {
     int m, n, nw;
     long long E;
-    const int* edge_col;   // [E]
-    const int* col_edge;   // [E]
+    // Tables built once per code on the host (ldpc_amd.hip, build_resident_tables):
+    const int* perm;       // [n]  variable handled at VN position p (thread p % nt, step p / nt)
+    const int* pos_of_var; // [n]  inverse of perm
+    const int* vn_off;     // [n*DV] byte offset in msg of edge k of the variable at position p, [p*DV + k]
+    const int* edge_slot;  // [E]  LDS slot of CSR edge e
+    const int* edge_pos;   // [E]  VN position of the variable of CSR edge e (its decision bit index)
     const float* llr;      // [frames][n] channel LLRs, or null
     const uint8_t* r;      // [frames][n] hard received words (then lambda = +-l0 / +-l1), or null
     float l0, l1;          // already in the rule's LLR unit
@@ -39,46 +43,17 @@ struct LdsParams {
     int32_t* out_synd;     // [frames] or null
 };
 
-// LDS slot of CSR edge e = (check i, position k).  With PAIR the rows of the two checks a thread
-// processes together (i = t + c*nt for c = 2q, 2q+1) are interleaved element by element, so that
+// LDS slot of CSR edge e = (check i, position k): the rows of the two checks a thread processes
+// together (i = t + c*nt for c = 2q, 2q+1) are interleaved element by element, so that
 // (check 2q position k, check 2q+1 position k) is one aligned 8-byte pair = one packed register.
-template <int DC, bool PAIR>
-__device__ __forceinline__ int lds_slot(int e, int nt) {
-    if constexpr (!PAIR) {
-        return e;
-    } else {
-        const int i = e / DC, k = e - i * DC;
-        const int c = i / nt, t = i - c * nt;
-        return 2 * DC * (t + (c >> 1) * nt) + 2 * k + (c & 1);
-    }
+__host__ __device__ inline int lds_slot(int e, int dc, int nt) {
+    const int i = e / dc, k = e - i * dc;
+    const int c = i / nt, t = i - c * nt;
+    return 2 * dc * (t + (c >> 1) * nt) + 2 * k + (c & 1);
 }
 
-template <int DC>
-__device__ __forceinline__ void lds_load_row(const float* p, float (&x)[DC]) {
-    if constexpr (DC % 2 == 0) {
-#pragma unroll
-        for (int q = 0; q < DC / 2; ++q) {
-            const float2 v = reinterpret_cast<const float2*>(p)[q];
-            x[2 * q] = v.x;
-            x[2 * q + 1] = v.y;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < DC; ++k) x[k] = p[k];
-    }
-}
-template <int DC>
-__device__ __forceinline__ void lds_store_row(float* p, const float (&x)[DC]) {
-    if constexpr (DC % 2 == 0) {
-#pragma unroll
-        for (int q = 0; q < DC / 2; ++q) reinterpret_cast<float2*>(p)[q] = make_float2(x[2 * q], x[2 * q + 1]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < DC; ++k) p[k] = x[k];
-    }
-}
-
-// number of unsatisfied checks of the decisions in `bits` (sumSyndro, LogDecoder.java:108-116)
+// number of unsatisfied checks of the decisions in `bits` (sumSyndro, LogDecoder.java:108-116);
+// bits are indexed by VN position, edge_pos maps an edge to the position of its variable
 template <int DC>
 __device__ __forceinline__ int lds_syndrome(const LdsParams& p, const uint32_t* bits, int* red, int t, int nt) {
     int cnt = 0;
@@ -86,8 +61,8 @@ __device__ __forceinline__ int lds_syndrome(const LdsParams& p, const uint32_t* 
         uint32_t par = 0u;
 #pragma unroll
         for (int k = 0; k < DC; ++k) {
-            const int j = p.edge_col[(long long)i * DC + k];
-            par ^= bits[j >> 5] >> (j & 31);
+            const int q = p.edge_pos[(long long)i * DC + k];
+            par ^= bits[q >> 5] >> (q & 31);
         }
         cnt += (int)(par & 1u);
     }
@@ -101,79 +76,76 @@ __device__ __forceinline__ int lds_syndrome(const LdsParams& p, const uint32_t* 
     return total;
 }
 
-// CPT checks and kLdsVpt variables per thread, exactly: m = CPT * blockDim.x, n = kLdsVpt * blockDim.x.
+// CPT (even) checks and kLdsVpt variables per thread, exactly: m = CPT * blockDim.x, n = kLdsVpt * blockDim.x.
 template <int DC, int DV, int RULE, bool EARLY, int CPT>
 __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
+    static_assert(CPT % 2 == 0, "checks are processed in pairs");
     extern __shared__ __align__(16) float smem[];
     float* msg = smem;                                   // [E]
-    float* lam = smem + p.E;                             // [n]
-    uint32_t* bits = reinterpret_cast<uint32_t*>(lam + p.n);  // [nw]
+    float* lam = smem + p.E;                             // [n], by VN position
+    uint32_t* bits = reinterpret_cast<uint32_t*>(lam + p.n);  // [nw], by VN position
     int* red = reinterpret_cast<int*>(bits + p.nw);      // syndrome accumulator
     const int t = threadIdx.x, nt = blockDim.x;
     const long long frame = blockIdx.x;
     if (frame >= p.frames) return;
-    constexpr bool PAIR = (RULE == kCnLogTanh) && (CPT % 2 == 0);
     char* msgb = reinterpret_cast<char*>(msg);
 
-    // this thread's variables and the byte offsets of their edge slots in msg
+    // byte offsets of the edge slots of this thread's variables: fixed for the whole decode
     int off[kLdsVpt][DV];
 #pragma unroll
-    for (int v = 0; v < kLdsVpt; ++v) {
-        const int j = t + v * nt;
+    for (int v = 0; v < kLdsVpt; ++v)
 #pragma unroll
-        for (int k = 0; k < DV; ++k) off[v][k] = 4 * lds_slot<DC, PAIR>(p.col_edge[(long long)j * DV + k], nt);
-    }
-    // channel LLRs of the frame -> LDS
+        for (int k = 0; k < DV; ++k) off[v][k] = p.vn_off[(long long)(t + v * nt) * DV + k];
+    // channel LLRs of the frame -> LDS, in VN position order
     if (p.llr) {
         const float* src = p.llr + frame * p.n;
-        for (int j = t; j < p.n; j += nt) lam[j] = src[j] * p.scale;
+        for (int q = t; q < p.n; q += nt) lam[q] = src[p.perm[q]] * p.scale;
     } else {
         const uint8_t* src = p.r + frame * p.n;
-        for (int j = t; j < p.n; j += nt) {
+        for (int q = t; q < p.n; q += nt) {
+            const int j = p.perm[q];
             const float mag = (j < p.g_length) ? p.l0 : p.l1;  // LogDecoder.java:49-54
-            lam[j] = (src[j] == 0) ? mag : -mag;
+            lam[q] = (src[j] == 0) ? mag : -mag;
         }
     }
     if (t == 0) *red = 0;
     __syncthreads();
     // beta of the first iteration: lambda + the zero-initialised alpha (LogDecoder.java:57, :70-77)
-    for (int e = t; e < (int)p.E; e += nt) msg[lds_slot<DC, PAIR>(e, nt)] = lam[p.edge_col[e]] + 0.0f;
+    for (int e = t; e < (int)p.E; e += nt) msg[p.edge_slot[e]] = lam[p.edge_pos[e]] + 0.0f;
     __syncthreads();
 
     int iters = p.max_iters, synd = 0;
     for (int it = 0; it < p.max_iters; ++it) {
-        // check nodes: beta -> alpha in place
-        if constexpr (PAIR) {
-            // two checks per step in the two halves of packed fp32 registers
-            // (all rows are read before any is written back: distinct checks never share a slot)
-            v2f x[CPT / 2][DC];
+        // check nodes: beta -> alpha in place, two checks per step in the halves of packed registers
+        // (all rows are read before any is written back: distinct checks never share a slot)
+        v2f x[CPT / 2][DC];
 #pragma unroll
-            for (int q = 0; q < CPT / 2; ++q) {
-                const v2f* row = reinterpret_cast<const v2f*>(msg + 2 * DC * (t + q * nt));
+        for (int q = 0; q < CPT / 2; ++q) {
+            const v2f* row = reinterpret_cast<const v2f*>(msg + 2 * DC * (t + q * nt));
 #pragma unroll
-                for (int k = 0; k < DC; ++k) x[q][k] = row[k];
-            }
+            for (int k = 0; k < DC; ++k) x[q][k] = row[k];
+        }
 #pragma unroll
-            for (int q = 0; q < CPT / 2; ++q) {
-                v2f* row = reinterpret_cast<v2f*>(msg + 2 * DC * (t + q * nt));
+        for (int q = 0; q < CPT / 2; ++q) {
+            v2f* row = reinterpret_cast<v2f*>(msg + 2 * DC * (t + q * nt));
+            if constexpr (RULE == kCnLogTanh) {
                 cn_logtanh<v2f, DC>(x[q]);
+            } else {
+                float xa[DC], xb[DC];
 #pragma unroll
-                for (int k = 0; k < DC; ++k) row[k] = x[q][k];
-            }
-        } else {
+                for (int k = 0; k < DC; ++k) { xa[k] = x[q][k].x; xb[k] = x[q][k].y; }
+                cn_compute1<DC, RULE>(xa);
+                cn_compute1<DC, RULE>(xb);
 #pragma unroll
-            for (int c = 0; c < CPT; ++c) {
-                float* r0 = msg + (t + c * nt) * DC;
-                float x[DC];
-                lds_load_row<DC>(r0, x);
-                cn_compute1<DC, RULE>(x);
-                lds_store_row<DC>(r0, x);
+                for (int k = 0; k < DC; ++k) x[q][k] = v2f{xa[k], xb[k]};
             }
+#pragma unroll
+            for (int k = 0; k < DC; ++k) row[k] = x[q][k];
         }
         __syncthreads();
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit
-        const bool write_beta = EARLY || (it + 1 < p.max_iters);
         // (all gathers are issued before any scatter: distinct variables never share a slot)
+        const bool write_beta = EARLY || (it + 1 < p.max_iters);
         float va[kLdsVpt][DV][1], vl[kLdsVpt][1];
 #pragma unroll
         for (int v = 0; v < kLdsVpt; ++v) {
@@ -183,20 +155,18 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
         }
 #pragma unroll
         for (int v = 0; v < kLdsVpt; ++v) {
-            const int j = t + v * nt;
-            float (&a)[DV][1] = va[v];
-            float (&l)[1] = vl[v];
+            const int q = t + v * nt;
             float g[1];
-            vn_compute<1, DV>(a, l, g);
+            vn_compute<1, DV>(va[v], vl[v], g);
             if (write_beta) {
 #pragma unroll
-                for (int k = 0; k < DV; ++k) *reinterpret_cast<float*>(msgb + off[v][k]) = a[k][0];
+                for (int k = 0; k < DV; ++k) *reinterpret_cast<float*>(msgb + off[v][k]) = va[v][k][0];
             }
             if (EARLY || it + 1 == p.max_iters) {
                 const unsigned long long mask = __ballot(g[0] < 0.0f);  // "(gamma[j] < 0) ? 1 : 0", :104
-                if ((t & 63) == 0) {  // j is a multiple of 64 here and n a multiple of 64
-                    bits[j >> 5] = (uint32_t)mask;
-                    bits[(j >> 5) + 1] = (uint32_t)(mask >> 32);
+                if ((t & 63) == 0) {  // q is a multiple of 64 here and n a multiple of 64
+                    bits[q >> 5] = (uint32_t)mask;
+                    bits[(q >> 5) + 1] = (uint32_t)(mask >> 32);
                 }
             }
         }
@@ -214,12 +184,16 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
     uint8_t* out = p.hard + frame * p.n;
     if ((p.n & 3) == 0) {
         for (int j4 = t; j4 < (p.n >> 2); j4 += nt) {
-            const int j = j4 << 2;
-            const uint32_t w = bits[j >> 5] >> (j & 31);
-            reinterpret_cast<uchar4*>(out)[j4] = make_uchar4(w & 1u, (w >> 1) & 1u, (w >> 2) & 1u, (w >> 3) & 1u);
+            const int4 q = reinterpret_cast<const int4*>(p.pos_of_var)[j4];
+            reinterpret_cast<uchar4*>(out)[j4] =
+                make_uchar4((bits[q.x >> 5] >> (q.x & 31)) & 1u, (bits[q.y >> 5] >> (q.y & 31)) & 1u,
+                            (bits[q.z >> 5] >> (q.z & 31)) & 1u, (bits[q.w >> 5] >> (q.w & 31)) & 1u);
         }
     } else {
-        for (int j = t; j < p.n; j += nt) out[j] = (uint8_t)((bits[j >> 5] >> (j & 31)) & 1u);
+        for (int j = t; j < p.n; j += nt) {
+            const int q = p.pos_of_var[j];
+            out[j] = (uint8_t)((bits[q >> 5] >> (q & 31)) & 1u);
+        }
     }
     if (t == 0) {
         if (p.out_iters) p.out_iters[frame] = iters;

@@ -41,11 +41,16 @@ struct ldpc_amd_ctx {
     size_t stage_bytes[4] = {0, 0, 0, 0};
     unsigned long long* d_counters = nullptr;
     size_t counters_len = 0;
+    // tables of the frame-resident engine (built on first use, see build_resident_tables)
+    int res_nt = 0;
+    int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E] | edge_slot[E] | edge_pos[E]
+    double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
     // timing of the last decode
     std::vector<hipEvent_t> ev;
     int timed_launches = 0;
     long long timed_frames = 0;
     hipStream_t timed_stream = nullptr;
+    const char* last_kernel = "";  // which message-passing kernel the last decode ran
     std::string err;
 };
 
@@ -141,6 +146,85 @@ int ensure_stage(ldpc_amd_ctx* c, int slot, size_t bytes) {
     return LDPC_AMD_OK;
 }
 
+// Tables of the frame-resident engine.  Variables are assigned to VN positions (thread p % nt, step
+// p / nt) so that the 32 lanes of a half wavefront, which the LDS serves together for 4-byte
+// accesses, find their k-th edge slots in 32 different banks (bank = dword address mod 32): a greedy
+// fill, group by group.  The assignment only changes which lane owns which variable; every
+// variable still sums its own edges in ascending check order.
+int build_resident_tables(ldpc_amd_ctx* c, int nt) {
+    if (c->d_res && c->res_nt == nt) return LDPC_AMD_OK;
+    const int n = c->n, dc = c->reg_dc, dv = c->reg_dv;
+    const long long E = c->E;
+    std::vector<int> slot((size_t)E);
+    for (long long e = 0; e < E; ++e) slot[(size_t)e] = lds_slot((int)e, dc, nt);
+    std::vector<int> perm((size_t)n), pos((size_t)n);
+    std::vector<char> taken((size_t)n, 0);
+    std::vector<int> order((size_t)n);
+    for (int j = 0; j < n; ++j) order[(size_t)j] = j;
+    int first_free = 0;
+    long long mult_sum = 0, mult_cnt = 0;
+    for (int g = 0; g < n / 32; ++g) {
+        // group g = positions with step v = g / (nt/32) and lanes [32 h, 32 h + 32), h = g % (nt/32)
+        const int v = g / (nt / 32), h = g % (nt / 32);
+        // pass L admits a variable only if none of its banks would be used more than L times
+        unsigned char cnt[8][32];
+        memset(cnt, 0, sizeof(cnt));
+        int got = 0;
+        int members[32];
+        while (first_free < n && taken[(size_t)first_free]) ++first_free;
+        for (int level = 1; level <= 32 && got < 32; ++level) {
+            for (int j = first_free; j < n && got < 32; ++j) {
+                if (taken[(size_t)j]) continue;
+                bool ok = true;
+                for (int k = 0; k < dv && ok; ++k)
+                    ok = cnt[k][slot[(size_t)c->h_col_edge[(size_t)j * dv + k]] & 31] < level;
+                if (!ok) continue;
+                for (int k = 0; k < dv; ++k) ++cnt[k][slot[(size_t)c->h_col_edge[(size_t)j * dv + k]] & 31];
+                taken[(size_t)j] = 1;
+                members[got++] = j;
+            }
+        }
+        for (int l = 0; l < 32; ++l) {
+            const int p = (32 * h + l) + v * nt;
+            perm[(size_t)p] = members[l];
+            pos[(size_t)members[l]] = p;
+        }
+        for (int k = 0; k < dv; ++k) {  // statistics: worst bank multiplicity of this group's k-th gather
+            int worst = 0;
+            for (int b = 0; b < 32; ++b) worst = std::max(worst, (int)cnt[k][b]);
+            mult_sum += worst;
+            ++mult_cnt;
+        }
+    }
+    c->res_conflict = mult_cnt ? (double)mult_sum / (double)mult_cnt : 1.0;
+    std::vector<int> tab((size_t)(2 * n) + (size_t)(3 * E));
+    int* t_perm = tab.data();
+    int* t_pos = t_perm + n;
+    int* t_vn = t_pos + n;
+    int* t_slot = t_vn + E;
+    int* t_epos = t_slot + E;
+    for (int p = 0; p < n; ++p) {
+        t_perm[p] = perm[(size_t)p];
+        t_pos[p] = pos[(size_t)p];
+        for (int k = 0; k < dv; ++k) t_vn[(size_t)p * dv + k] = 4 * slot[(size_t)c->h_col_edge[(size_t)perm[(size_t)p] * dv + k]];
+    }
+    for (long long e = 0; e < E; ++e) {
+        t_slot[e] = slot[(size_t)e];
+        t_epos[e] = pos[(size_t)c->h_edge_col[(size_t)e]];
+    }
+    if (c->d_res) {
+        LDPC_HIP(c, hipFree(c->d_res));
+        c->d_res = nullptr;
+    }
+    LDPC_HIP(c, hipMalloc((void**)&c->d_res, tab.size() * sizeof(int)));
+    LDPC_HIP(c, hipMemcpy(c->d_res, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->res_nt = nt;
+    if (getenv("LDPC_AMD_VERBOSE"))
+        fprintf(stderr, "ldpc_amd: resident tables nt=%d, mean worst bank multiplicity of VN gathers %.3f\n", nt,
+                c->res_conflict);
+    return LDPC_AMD_OK;
+}
+
 constexpr int kLdsMaxDegree = 128;  // 2 arrays x 128 rows x 256 B = 64 KiB per wave
 
 enum class Src { Float, Bsc };
@@ -203,9 +287,11 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             if (!strcmp(env, "stream")) use = false;
         }
         if (use) {
+            if (int rc = build_resident_tables(c, nt)) return rc;
             LdsParams q{};
             q.m = c->m; q.n = n; q.nw = c->nw; q.E = c->E;
-            q.edge_col = c->d_edge_col; q.col_edge = c->d_col_edge;
+            q.perm = c->d_res; q.pos_of_var = q.perm + n; q.vn_off = q.pos_of_var + n;
+            q.edge_slot = q.vn_off + c->E; q.edge_pos = q.edge_slot + c->E;
             q.llr = src.kind == Src::Float ? src.llr : nullptr;
             q.r = src.kind == Src::Bsc ? src.r : nullptr;
             q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
@@ -226,6 +312,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             LDPC_HIP(c, hipEventRecord(c->ev[1], s));
             c->timed_launches = 1;
             c->timed_frames = frames;
+            c->last_kernel = "bp_lds_kernel";
             return LDPC_AMD_OK;
         }
     }
@@ -265,6 +352,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         LDPC_HIP(c, hipMalloc(&c->ws, need));
         c->ws_bytes = need;
     }
+    c->last_kernel = "bp_decode_kernel";
     while ((long long)c->ev.size() < 2 * std::min<long long>(rounds, 256)) {
         hipEvent_t e;
         LDPC_HIP(c, hipEventCreate(&e));
@@ -461,7 +549,7 @@ int ldpc_amd_destroy(ldpc_amd_ctx* c) {
         DeviceGuard guard(c->device);
         (void)hipDeviceSynchronize();
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-        void* ptrs[] = {c->d_row_ptr, c->d_edge_col, c->d_col_ptr, c->d_col_edge, c->ws,
+        void* ptrs[] = {c->d_row_ptr, c->d_edge_col, c->d_col_ptr, c->d_col_edge, c->ws, c->d_res,
                         c->stage[0],  c->stage[1],   c->stage[2],  c->stage[3],   c->d_counters};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -662,6 +750,8 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
     for (size_t i = 0; i < nc; ++i) counters[i] += h[i];
     return LDPC_AMD_OK;
 }
+
+const char* ldpc_amd_last_decode_kernel(const ldpc_amd_ctx* c) { return c ? c->last_kernel : ""; }
 
 int ldpc_amd_last_decode_timing(ldpc_amd_ctx* c, int32_t* launches, double* kernel_ms, int64_t* frames) {
     if (!c) return LDPC_AMD_EINVAL;
