@@ -1,0 +1,108 @@
+"""The other BASELINE configurations as parity cases on the GPU: the NR-BG1-sized irregular code read
+from a file in the reference's H format (config 4), the long n = 64800 code with a small batch and
+early termination (config 5), and an Eb/N0 sweep whose frame/bit error rates must sit inside the
+95 % confidence interval of the CPU oracle's (config 3, on a short code so the oracle keeps up)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _syndrome_weight_sparse(m, rows, cols, hard):
+    w = np.zeros((hard.shape[0], m), np.int64)
+    np.add.at(w, (slice(None), rows), hard[:, cols].astype(np.int64))
+    return (w % 2).sum(axis=1)
+
+
+def test_config4_bg1_sized_code_from_file(tmp_path, pkg, oracle):
+    base, (m, n, rows, cols) = pkg.codes.nr_bg1_shaped(z=384, seed=1)
+    path = tmp_path / "bg1_z384.txt"
+    pkg.check_matrix_io.save_check_matrix(str(path), m, n, rows, cols)
+    m2, n2, r2, c2 = pkg.check_matrix_io.load_check_matrix(str(path))
+    assert (m2, n2) == (17664, 26112) and (r2 == rows).all() and (c2 == cols).all()
+    dec = pkg.Decoder(m2, n2, r2, c2)
+    assert dec.E == 121344 and dec.max_dc == 19 and dec.max_dv == 30
+    g = oracle.Graph(m, n, rows, cols)
+    F = 96
+    llr = oracle.gen_awgn_llr(m, n, 2.0, seed=4, first_frame=0, frames=F)
+    for early, L in ((True, 25), (False, 8)):
+        got = dec.decode_batch(llr, L, early)
+        want = g.decode_llr_batch(llr, L, early)
+        assert (got[0] == want[0]).all(), "hard decisions differ from the oracle"
+        assert (got[1] == want[1]).all() and (got[2] == want[2]).all()
+        assert (_syndrome_weight_sparse(m, rows, cols, got[0]) == got[2]).all()
+    # a batch the oracle could not keep up with: properties only
+    import torch
+    F = 4096
+    d_llr = torch.empty((F, n), dtype=torch.float32, device="cuda")
+    dec.gen_awgn_llr_dev(2.0, 9, 0, F, d_llr.data_ptr())
+    d_hard = torch.empty((F, n), dtype=torch.uint8, device="cuda")
+    d_it = torch.empty(F, dtype=torch.int32, device="cuda")
+    d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
+    dec.decode_batch_dev(d_llr.data_ptr(), F, 50, True, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
+    torch.cuda.synchronize()
+    it, sw, hard = d_it.cpu().numpy(), d_sw.cpu().numpy(), d_hard.cpu().numpy()
+    assert ((sw == 0) == (it < 50) | (sw == 0)).all()
+    conv = sw == 0
+    assert conv.mean() > 0.5
+    assert hard[conv].sum() == 0          # converged frames return the transmitted all-zero word here
+    assert (_syndrome_weight_sparse(m, rows, cols, hard[:256]) == sw[:256]).all()
+
+
+def test_config5_long_code_small_batch_early_exit(pkg, oracle):
+    m, n, rows, cols = pkg.codes.regular_ldpc(64800, 3, 6, seed=1)
+    dec = pkg.Decoder(m, n, rows, cols)
+    g = oracle.Graph(m, n, rows, cols)
+    for F in (1, 8):
+        llr = oracle.gen_awgn_llr(m, n, 1.6, seed=6, first_frame=0, frames=F)
+        got = dec.decode_batch(llr, 50, True)
+        want = g.decode_llr_batch(llr, 50, True)
+        assert (got[0] == want[0]).all()
+        assert (got[1] == want[1]).all() and (got[2] == want[2]).all()
+        assert (got[1] < 50).all() and (got[2] == 0).all()
+
+
+def _ci95(k, nobs):
+    """Wilson 95 % interval for k successes in nobs trials."""
+    if nobs == 0:
+        return 0.0, 1.0
+    z = 1.959964
+    ph = k / nobs
+    den = 1 + z * z / nobs
+    mid = (ph + z * z / (2 * nobs)) / den
+    half = z * math.sqrt(ph * (1 - ph) / nobs + z * z / (4 * nobs * nobs)) / den
+    return max(0.0, mid - half), min(1.0, mid + half)
+
+
+def test_config3_ebn0_sweep_inside_oracle_confidence_intervals(pkg, oracle):
+    """FER and info-BER of the GPU Monte-Carlo leg against the CPU oracle's over an Eb/N0 sweep,
+    frames sharded over two 'ranks' by global index (the counters of the shards must add up)."""
+    m, n, rows, cols = pkg.codes.regular_ldpc(1024, 3, 6, seed=2)
+    dec = pkg.Decoder(m, n, rows, cols)
+    g = oracle.Graph(m, n, rows, cols)
+    k = n - m
+    rows_out = []
+    for ebn0 in (1.0, 1.5, 2.0, 2.5):
+        FO, FG = 3000, 60000
+        want = g.simulate(oracle.CH_AWGN, ebn0, seed=77, first_frame=0, frames=FO, max_iters=50)
+        a_start, a_cnt = pkg.sim.shard_range(0, FG, 0, 2)
+        b_start, b_cnt = pkg.sim.shard_range(0, FG, 1, 2)
+        got = dec.simulate(pkg.capi.CH_AWGN, ebn0, 77, a_start, a_cnt, 50) + \
+            dec.simulate(pkg.capi.CH_AWGN, ebn0, 77, b_start, b_cnt, 50)
+        assert got[0] == FG and want[0] == FO
+        fer_g = got[1] / FG
+        lo, hi = _ci95(int(want[1]), FO)
+        rows_out.append((ebn0, fer_g, int(want[1]) / FO, lo, hi))
+        assert lo <= fer_g <= hi, "FER %.5f outside the oracle's 95%% interval [%.5f, %.5f] at %.1f dB" % (fer_g, lo, hi, ebn0)
+        # channel BER is set by the channel alone: both estimates bracket Q(sqrt(2 R Eb/N0))
+        pch = 0.5 * math.erfc(math.sqrt(0.5 * 10 ** (ebn0 / 10)))
+        assert abs(got[10] / (FG * k) - pch) < 4 * math.sqrt(pch / (FG * k))
+        assert abs(want[10] / (FO * k) - pch) < 4 * math.sqrt(pch / (FO * k))
+        # mean iterations of the frames that decode agree to a few percent
+        if got[0] - got[1] and want[0] - want[1]:
+            ig = got[8] / (got[0] - got[1])
+            io = want[8] / (want[0] - want[1])
+            assert abs(ig - io) < 0.05 * io + 0.2
+    print("Eb/N0, GPU FER, oracle FER, oracle 95% CI:", rows_out)
