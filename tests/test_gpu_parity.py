@@ -343,3 +343,28 @@ def test_full_size_properties_c2(c2, oracle):
     w = (d_hard.float() @ H.T).remainder(2).sum(dim=1).int()
     assert (w == d_sw).all()
     assert (d_sw > 0).any() and (d_sw == 0).any()
+
+
+def test_hard_decision_agreement_at_scale(c1, c2, oracle, engine):
+    """The >= 99.99 % bar on a sample large enough to resolve it: every frame's hard decisions
+    against the double-precision oracle on identical LLRs, early termination as in the reference.
+    Frames whose triple (word, iterations, syndrome weight) differs are itemised."""
+    if engine != "resident":
+        pytest.skip("both engines return identical bits (test_engines_return_identical_bits)")
+    total = hard_bad = triple_bad = 0
+    notes = []
+    for c, ebn0, F in ((c2, 2.0, 16000), (c2, 1.4, 8000), (c1, 4.5, 30000), (c1, 3.5, 10000)):
+        llr = oracle.gen_awgn_llr(c["m"], c["n"], ebn0, seed=31, first_frame=0, frames=F)
+        got = c["dec"].decode_batch(llr, 50, True)
+        want = c["g"].decode_llr_batch(llr, 50, True)
+        _, hd = _hard_agreement(got, want)
+        _, td = _agreement(got, want)
+        total += F
+        hard_bad += hd.size
+        triple_bad += td.size
+        notes.append((c["n"], ebn0, F, hd.size, td.size, got[1][td[:6]].tolist(), want[1][td[:6]].tolist(),
+                      float((want[2] > 0).mean())))
+    print("frames %d, hard decisions differ on %d, triples on %d; per case (n, dB, frames, hard, triple, "
+          "gpu iters, oracle iters, oracle failure rate): %s" % (total, hard_bad, triple_bad, notes))
+    assert hard_bad <= total * 1e-4, notes
+    assert triple_bad <= total * 5e-4, notes
