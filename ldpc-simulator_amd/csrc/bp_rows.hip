@@ -1,0 +1,48 @@
+// Row-parallel sweep launches (see bp_rows.hpp).
+#define LDPC_ROWS_KERNELS
+#include "bp_rows.hpp"
+
+namespace ldpc {
+
+namespace {
+
+template <int FPL>
+void launch_cn(const RowsLaunch& l, const RowsParams& p, dim3 grid, dim3 block, bool first) {
+#define LDPC_CN(R)                                                                                          \
+    if (first) hipLaunchKernelGGL((rows_cn_kernel<FPL, R, true>), grid, block, l.lds_bytes, l.stream, p);   \
+    else       hipLaunchKernelGGL((rows_cn_kernel<FPL, R, false>), grid, block, l.lds_bytes, l.stream, p)
+    switch (l.rule) {
+        case kCnMinSum: LDPC_CN(kCnMinSum); break;
+        case kCnSumProduct: LDPC_CN(kCnSumProduct); break;
+        default: LDPC_CN(kCnLogTanh); break;
+    }
+#undef LDPC_CN
+}
+
+template <int FPL>
+hipError_t run(const RowsLaunch& l, RowsParams p) {
+    const dim3 block((unsigned)(64 * l.wpb));
+    const dim3 grid((unsigned)((l.chunks + l.wpb - 1) / l.wpb), (unsigned)p.b.tiles);
+    const int slots = p.b.tiles * kWave * FPL;
+    const dim3 sgrid((unsigned)((slots + 255) / 256));
+    for (int it = 0; it < p.b.max_iters; ++it) {
+        p.iter = it;
+        const bool last = it + 1 == p.b.max_iters;
+        launch_cn<FPL>(l, p, grid, block, it == 0);
+        hipLaunchKernelGGL((rows_vn_kernel<FPL>), grid, block, l.lds_bytes, l.stream, p, (p.early || !last) ? 1 : 0);
+        if (p.early || last) {
+            hipLaunchKernelGGL((rows_synd_kernel<FPL>), grid, block, 0, l.stream, p);
+            hipLaunchKernelGGL(rows_finish_kernel, sgrid, dim3(256), 0, l.stream, p, slots, last ? 1 : 0);
+        }
+    }
+    hipLaunchKernelGGL(rows_export_kernel, sgrid, dim3(256), 0, l.stream, p, slots);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t bp_rows_run(const RowsLaunch& l, RowsParams p) {
+    return l.fpl == 4 ? run<4>(l, p) : run<1>(l, p);
+}
+
+}  // namespace ldpc

@@ -1,0 +1,166 @@
+// Row-parallel sweeps: the streaming engine for batches too small to give every CU its own tiles.
+//
+// bp_decode_kernel gives one wavefront one tile of frames for the whole decode, which needs thousands
+// of tiles to fill 256 CUs.  A long code with a small batch (n = 64800 with 64 frames is ONE tile) has
+// the parallelism elsewhere: the checks of one sweep are independent of each other, and so are the
+// variables.  Here every sweep is its own launch over (tile, row chunk) pairs -- the launch boundary is
+// the grid-wide barrier between the CN and the VN sweep -- on the same frame-major arrays and with the
+// same per-row code (cn_dispatch / vn_dispatch of bp_kernels.hpp), so the bits are identical to the
+// one-launch kernel's.  Per-frame early termination lives in small state arrays between launches.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bp_kernels.hpp"
+
+namespace ldpc {
+
+struct RowsParams {
+    BpParams b;          // graph, workspace arrays, strides, tiles, frame_base, frames_total, max_iters
+    int rows_per_chunk;  // checks per wave in a CN / syndrome launch
+    int vars_per_chunk;  // variables per wave in a VN launch, a multiple of 32
+    int iter;            // iteration this launch belongs to (0-based)
+    int early;           // per-frame early termination
+    int32_t* st_done;    // [tiles*T] 0 = still iterating (early mode)
+    int32_t* st_acc;     // [tiles*T] syndrome weight accumulator of the current iteration
+    int32_t* st_iters;   // [tiles*T]
+    int32_t* st_synd;    // [tiles*T]
+};
+
+#ifdef LDPC_ROWS_KERNELS  // the kernels are compiled in bp_rows.hip only
+
+template <int FPL>
+__device__ __forceinline__ bool rows_lane_active(const RowsParams& p, int tile, int lane) {
+    // FPL > 1 only runs without early termination; with FPL == 1 a finished frame's lane sits out
+    if constexpr (FPL == 1) return !p.early || p.st_done[(long long)tile * kWave + lane] == 0;
+    return true;
+}
+
+template <int FPL, int RULE, bool FIRST>
+__global__ void __launch_bounds__(256, 4) rows_cn_kernel(RowsParams p) {
+    extern __shared__ float lds_all[];
+    float* lds = lds_all + (long long)(threadIdx.x >> 6) * 2 * p.b.lds_maxd * 64;
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int tile = blockIdx.y;
+    const int i0 = chunk * p.rows_per_chunk;
+    if (i0 >= p.b.m) return;
+    const int i1 = min(p.b.m, i0 + p.rows_per_chunk);
+    float* msg = p.b.ws_msg + (long long)tile * p.b.msg_tile + lane * FPL;
+    const float* lam = p.b.ws_lam + (long long)tile * p.b.lam_tile + lane * FPL;
+    if (rows_lane_active<FPL>(p, tile, lane)) {
+        for (int i = i0; i < i1; ++i) {
+            const int e0 = p.b.row_ptr[i];
+            const int d = p.b.row_ptr[i + 1] - e0;
+            cn_dispatch<FPL, RULE, FIRST>(d, msg + (long long)e0 * p.b.msg_row, lam, p.b.edge_col + e0, p.b.msg_row,
+                                          p.b.lam_row, lds, p.b.lds_maxd, lane);
+        }
+    }
+}
+
+template <int FPL>
+__global__ void __launch_bounds__(256, 4) rows_vn_kernel(RowsParams p, int write_beta) {
+    extern __shared__ float lds_all[];
+    float* lds = lds_all + (long long)(threadIdx.x >> 6) * 2 * p.b.lds_maxd * 64;
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int tile = blockIdx.y;
+    const int j0 = chunk * p.vars_per_chunk;
+    if (j0 >= p.b.n) return;
+    const int j1 = min(p.b.n, j0 + p.vars_per_chunk);
+    float* msg = p.b.ws_msg + (long long)tile * p.b.msg_tile + lane * FPL;
+    const float* lam = p.b.ws_lam + (long long)tile * p.b.lam_tile + lane * FPL;
+    uint32_t* bits = p.b.ws_bits + (long long)tile * p.b.bits_tile + lane * FPL;
+    if (!rows_lane_active<FPL>(p, tile, lane)) return;
+    uint32_t acc[FPL];
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) acc[f] = 0u;
+    for (int j = j0; j < j1; ++j) {
+        const int c0 = p.b.col_ptr[j];
+        const int d = p.b.col_ptr[j + 1] - c0;
+        float g[FPL];
+        vn_dispatch<FPL>(d, msg, lam + (long long)j * p.b.lam_row, p.b.col_edge + c0, p.b.msg_row, write_beta != 0, g,
+                         lds, p.b.lds_maxd, lane);
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) acc[f] |= (g[f] < 0.0f ? 1u : 0u) << (j & 31);  // "(gamma[j] < 0) ? 1 : 0", :104
+        if ((j & 31) == 31 || j == p.b.n - 1) {
+            stw<FPL>(bits + (long long)(j >> 5) * p.b.bits_row, acc);
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) acc[f] = 0u;
+        }
+    }
+}
+
+template <int FPL>
+__global__ void __launch_bounds__(256, 4) rows_synd_kernel(RowsParams p) {
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int tile = blockIdx.y;
+    const int i0 = chunk * p.rows_per_chunk;
+    if (i0 >= p.b.m) return;
+    const int i1 = min(p.b.m, i0 + p.rows_per_chunk);
+    const uint32_t* bits = p.b.ws_bits + (long long)tile * p.b.bits_tile + lane * FPL;
+    if (!rows_lane_active<FPL>(p, tile, lane)) return;
+    int w[FPL];
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) w[f] = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int e0 = p.b.row_ptr[i], e1 = p.b.row_ptr[i + 1];
+        uint32_t par[FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) par[f] = 0u;
+        for (int e = e0; e < e1; ++e) {
+            const int j = p.b.edge_col[e];
+            uint32_t v[FPL];
+            ldw<FPL>(bits + (long long)(j >> 5) * p.b.bits_row, v);
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) par[f] ^= v[f] >> (j & 31);
+        }
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) w[f] += (int)(par[f] & 1u);
+    }
+#pragma unroll
+    for (int f = 0; f < FPL; ++f)
+        if (w[f]) atomicAdd(&p.st_acc[(long long)tile * (kWave * FPL) + lane * FPL + f], w[f]);
+}
+
+// one thread per frame slot: close the iteration (LogDecoder.java:115-119)
+__global__ void __launch_bounds__(256) rows_finish_kernel(RowsParams p, int slots, int last) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots) return;
+    if (p.early && p.st_done[s]) return;
+    const int w = p.st_acc[s];
+    p.st_acc[s] = 0;
+    p.st_synd[s] = w;
+    if (p.early && w == 0) {
+        p.st_done[s] = 1;
+        p.st_iters[s] = p.iter + 1;
+    } else if (last) {
+        p.st_iters[s] = p.b.max_iters;
+    }
+}
+
+__global__ void __launch_bounds__(256) rows_export_kernel(RowsParams p, int slots) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots) return;
+    const long long frame = p.b.frame_base + s;
+    if (frame >= p.b.frames_total) return;
+    if (p.b.out_iters) p.b.out_iters[frame] = p.st_iters[s];
+    if (p.b.out_synd) p.b.out_synd[frame] = p.st_synd[s];
+}
+
+#endif  // LDPC_ROWS_KERNELS
+
+struct RowsLaunch {
+    int fpl;            // 1 or 4
+    int rule;
+    int chunks;         // row / variable chunks per tile
+    int wpb;            // waves per block (1 when rows are staged through LDS)
+    size_t lds_bytes;   // dynamic LDS per block
+    hipStream_t stream;
+};
+
+// All launches of one decode of the tiles in p.b (state arrays zeroed by the caller).
+hipError_t bp_rows_run(const RowsLaunch& l, RowsParams p);
+
+}  // namespace ldpc

@@ -16,6 +16,7 @@
 
 #include "bp_kernels.hpp"
 #include "bp_lds.hpp"
+#include "bp_rows.hpp"
 #include "io_kernels.hpp"
 
 using namespace ldpc;
@@ -330,7 +331,8 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     const size_t lds_bytes = use_lds ? (size_t)2 * lds_maxd * 64 * sizeof(float) : 0;
 
     const long long tiles_total = (frames + T - 1) / T;
-    const size_t per_tile = ((size_t)c->E + (size_t)n + (size_t)c->nw) * T * sizeof(float);
+    // + 4 words of per-frame state for the row-parallel launches
+    const size_t per_tile = ((size_t)c->E + (size_t)n + (size_t)c->nw + 4) * T * sizeof(float);
     unsigned long long limit = c->ws_limit;
     if (!limit) {
         size_t fr = 0, tot = 0;
@@ -376,6 +378,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     float* ws_msg = (float*)c->ws;
     float* ws_lam = ws_msg + (size_t)tiles_per_round * c->E * T;
     uint32_t* ws_bits = (uint32_t*)(ws_lam + (size_t)tiles_per_round * n * T);
+    int32_t* ws_state = (int32_t*)(ws_bits + (size_t)tiles_per_round * c->nw * T);
     p.ws_msg = ws_msg; p.ws_lam = ws_lam; p.ws_bits = ws_bits;
     p.frames_total = frames; p.max_iters = max_iters;
     p.out_iters = d_iters; p.out_synd = d_synd;
@@ -383,6 +386,17 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     if (const char* env = getenv("LDPC_AMD_SKIP")) p.skip = atoi(env);  // timing experiments only
     bool pipelined = true;
     if (const char* env = getenv("LDPC_AMD_NOPIPE")) pipelined = atoi(env) == 0;  // A/B: per-row dispatch kernels
+    // Too few tiles to give every CU its own: split every sweep over row chunks, one launch per sweep.
+    bool by_rows = tiles_per_round < 2048 && tiles_per_round <= 65535 && layout == 0 && fpl != 2;
+    if (const char* env = getenv("LDPC_AMD_ROWS")) by_rows = atoi(env) != 0 && tiles_per_round <= 65535 && layout == 0 && fpl != 2;
+    int chunks = 1, rows_per_chunk = c->m, vars_per_chunk = (n + 31) / 32 * 32;
+    if (by_rows) {
+        chunks = (int)std::min<long long>((8192 + tiles_per_round - 1) / tiles_per_round, 4096);
+        chunks = std::max(1, std::min(chunks, std::max(1, std::min(c->m / 4, n / 32))));
+        rows_per_chunk = (c->m + chunks - 1) / chunks;
+        vars_per_chunk = ((n + chunks - 1) / chunks + 31) / 32 * 32;
+        c->last_kernel = "rows_cn_kernel";
+    }
 
     for (long long r = 0; r < rounds; ++r) {
         const long long tile0 = r * tiles_per_round;
@@ -405,7 +419,24 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         }
         const bool timed = r < 256;
         if (timed) LDPC_HIP(c, hipEventRecord(c->ev[(size_t)(2 * r)], s));
-        if (int rc = launch_bp(c, p, fpl, early, wpb, lds_bytes, pipelined, s)) return rc;
+        if (by_rows) {
+            RowsParams q{};
+            q.b = p;
+            q.rows_per_chunk = rows_per_chunk;
+            q.vars_per_chunk = vars_per_chunk;
+            q.early = early ? 1 : 0;
+            const size_t slots = (size_t)tiles * T;
+            q.st_done = ws_state; q.st_acc = ws_state + slots; q.st_iters = ws_state + 2 * slots; q.st_synd = ws_state + 3 * slots;
+            LDPC_HIP(c, hipMemsetAsync(ws_state, 0, 4 * slots * sizeof(int32_t), s));
+            RowsLaunch l;
+            l.fpl = fpl == 4 ? 4 : 1;
+            l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
+                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnLogTanh;
+            l.chunks = chunks; l.wpb = wpb; l.lds_bytes = lds_bytes; l.stream = s;
+            LDPC_HIP(c, bp_rows_run(l, q));
+        } else if (int rc = launch_bp(c, p, fpl, early, wpb, lds_bytes, pipelined, s)) {
+            return rc;
+        }
         if (timed) {
             LDPC_HIP(c, hipEventRecord(c->ev[(size_t)(2 * r + 1)], s));
             c->timed_launches++;

@@ -13,20 +13,24 @@ import os
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["resident", "stream"])
+@pytest.fixture(autouse=True, params=["resident", "stream_tiles", "stream_rows"])
 def engine(request):
-    """Regular codes that fit in LDS run the frame-resident engine by default; every test also runs
-    with the frame-major streaming engine forced (LDPC_AMD_ENGINE=stream)."""
-    old = os.environ.get("LDPC_AMD_ENGINE")
-    if request.param == "stream":
+    """Regular codes that fit in LDS run the frame-resident engine by default.  Every test also runs
+    with the frame-major streaming engine forced (LDPC_AMD_ENGINE=stream), once as the one-launch
+    kernel that gives each wavefront its own tile (LDPC_AMD_ROWS=0) and once as row-parallel sweep
+    launches (LDPC_AMD_ROWS=1, the default for small batches)."""
+    keys = ("LDPC_AMD_ENGINE", "LDPC_AMD_ROWS")
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ.pop(k, None)
+    if request.param != "resident":
         os.environ["LDPC_AMD_ENGINE"] = "stream"
-    else:
-        os.environ.pop("LDPC_AMD_ENGINE", None)
+        os.environ["LDPC_AMD_ROWS"] = "1" if request.param == "stream_rows" else "0"
     yield request.param
-    if old is None:
-        os.environ.pop("LDPC_AMD_ENGINE", None)
-    else:
-        os.environ["LDPC_AMD_ENGINE"] = old
+    for k in keys:
+        os.environ.pop(k, None)
+        if old[k] is not None:
+            os.environ[k] = old[k]
 
 
 def _dense(m, n, rows, cols):
@@ -199,11 +203,16 @@ def test_engines_return_identical_bits(c1, c2, oracle, engine):
         for early, L in ((True, 30), (False, 9)):
             os.environ.pop("LDPC_AMD_ENGINE", None)
             a = c["dec"].decode_batch(llr, L, early)
+            assert c["dec"].last_decode_kernel() == "bp_lds_kernel"
             os.environ["LDPC_AMD_ENGINE"] = "stream"
-            b = c["dec"].decode_batch(llr, L, early)
+            for rows_mode, kernel in (("0", "bp_decode_kernel"), ("1", "rows_cn_kernel")):
+                os.environ["LDPC_AMD_ROWS"] = rows_mode
+                b = c["dec"].decode_batch(llr, L, early)
+                assert c["dec"].last_decode_kernel() == kernel
+                for x, y in zip(a, b):
+                    assert (x == y).all(), (early, L, kernel)
             os.environ.pop("LDPC_AMD_ENGINE", None)
-            for x, y in zip(a, b):
-                assert (x == y).all(), (early, L)
+            os.environ.pop("LDPC_AMD_ROWS", None)
             assert (a[2] > 0).any()
 
 
