@@ -27,10 +27,17 @@ constexpr int kWave = 64;
 constexpr int kCnSumProduct = 0;
 constexpr int kCnMinSum = 1;
 constexpr int kCnLogTanh = 2;
-#ifndef LDPC_REG_DEG_FPL1
-#define LDPC_REG_DEG_FPL1 16
+// node degrees handled in registers with 1 frame per lane (larger rows are staged through LDS);
+// a translation unit may raise them for its own kernels
+#ifndef LDPC_REG_DEG_CN
+#define LDPC_REG_DEG_CN 16
 #endif
-constexpr int kRegDegFpl1 = LDPC_REG_DEG_FPL1;  // node degrees handled in registers, 1 frame per lane
+#ifndef LDPC_REG_DEG_VN
+#define LDPC_REG_DEG_VN 16
+#endif
+constexpr int kRegDegCn = LDPC_REG_DEG_CN;
+constexpr int kRegDegVn = LDPC_REG_DEG_VN;
+constexpr int kRegDegFpl1 = 16;  // the one-launch kernels' limit for both
 constexpr int kRegDegFpl4 = 8;   // ... and with 2 or 4 frames per lane
 
 struct BpParams {
@@ -473,14 +480,14 @@ __device__ __forceinline__ float vn_col_lds(float* msg, const float* lamrow, con
 // ---- degree dispatch -------------------------------------------------------------------
 #define LDPC_CASE_CN(D)                                                              \
     case D:                                                                          \
-        if constexpr (D <= (FPL == 1 ? kRegDegFpl1 : kRegDegFpl4))                   \
+        if constexpr (D <= (FPL == 1 ? kRegDegCn : kRegDegFpl4))                     \
             cn_row<FPL, D, RULE, FIRST>(row, lam, cols, T, LT);                          \
         else if constexpr (FPL == 1)                                                 \
             cn_row_lds<RULE, FIRST>(row, lam, cols, T, LT, d, lds, cap, lane);           \
         break;
 #define LDPC_CASE_VN(D)                                                              \
     case D:                                                                          \
-        if constexpr (D <= (FPL == 1 ? kRegDegFpl1 : kRegDegFpl4))                   \
+        if constexpr (D <= (FPL == 1 ? kRegDegVn : kRegDegFpl4))                     \
             vn_col<FPL, D>(msg, lamrow, edges, T, write_beta, g);                    \
         else if constexpr (FPL == 1)                                                 \
             g[0] = vn_col_lds(msg, lamrow, edges, T, d, write_beta, lds, cap, lane); \

@@ -1,5 +1,8 @@
 // Row-parallel sweep launches (see bp_rows.hpp).
 #define LDPC_ROWS_KERNELS
+// these kernels keep checks up to degree 20 and variables up to degree 32 in registers
+#define LDPC_REG_DEG_CN 20
+#define LDPC_REG_DEG_VN 32
 #include "bp_rows.hpp"
 
 namespace ldpc {

@@ -151,6 +151,8 @@ __global__ void __launch_bounds__(256) rows_export_kernel(RowsParams p, int slot
 
 #endif  // LDPC_ROWS_KERNELS
 
+constexpr int kRowsRegDegCn = 20, kRowsRegDegVn = 32;  // register limits of the kernels in bp_rows.hip
+
 struct RowsLaunch {
     int fpl;            // 1 or 4
     int rule;

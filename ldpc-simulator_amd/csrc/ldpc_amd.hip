@@ -325,10 +325,11 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         if (!early && maxdeg <= kRegDegFpl4 && (v == 1 || v == 2 || v == 4)) fpl = v;
     }
     const int T = 64 * fpl;
-    const bool use_lds = maxdeg > kRegDegFpl1;
-    const int lds_maxd = use_lds ? maxdeg : 0;
-    const int wpb = use_lds ? 1 : 4;
-    const size_t lds_bytes = use_lds ? (size_t)2 * lds_maxd * 64 * sizeof(float) : 0;
+    // rows above the kernels' register limit are staged through LDS, one wave per block
+    bool use_lds = maxdeg > kRegDegFpl1;
+    int lds_maxd = use_lds ? maxdeg : 0;
+    int wpb = use_lds ? 1 : 4;
+    size_t lds_bytes = use_lds ? (size_t)2 * lds_maxd * 64 * sizeof(float) : 0;
 
     const long long tiles_total = (frames + T - 1) / T;
     // + 4 words of per-frame state for the row-parallel launches
@@ -396,6 +397,11 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         rows_per_chunk = (c->m + chunks - 1) / chunks;
         vars_per_chunk = ((n + chunks - 1) / chunks + 31) / 32 * 32;
         c->last_kernel = "rows_cn_kernel";
+        use_lds = c->max_dc > kRowsRegDegCn || c->max_dv > kRowsRegDegVn;
+        lds_maxd = use_lds ? maxdeg : 0;
+        wpb = use_lds ? 1 : 4;
+        lds_bytes = use_lds ? (size_t)2 * lds_maxd * 64 * sizeof(float) : 0;
+        p.lds_maxd = lds_maxd;
     }
 
     for (long long r = 0; r < rounds; ++r) {
