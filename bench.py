@@ -92,7 +92,11 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--ebn0", type=float, default=1.0)
     ap.add_argument("--n", type=int, default=4096)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--engine", choices=["auto", "stream"], default="auto",
+                    help="auto: frame-resident kernel when the code fits in LDS; stream: force the frame-major HBM kernel")
+    ap.add_argument("--no-stream-leg", action="store_true",
+                    help="skip the extra single-step measurement of the streaming engine (N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -112,6 +116,8 @@ def main():
 
     import ldpc_simulator_amd as L
 
+    if args.engine == "stream":
+        os.environ["LDPC_AMD_ENGINE"] = "stream"
     code = L.codes.regular_ldpc(args.n, 3, 6, seed=1)
     m, n, rows, cols = code
     dec = L.Decoder(m, n, rows, cols, device=local_rank)
@@ -204,6 +210,24 @@ def main():
         },
         "frame_error_rate": float(cnt[1]) / max(float(cnt[0]), 1.0),
     }
+    if world == 1 and kernel == "bp_lds_kernel" and not args.no_stream_leg:
+        # the same batch once through the frame-major HBM streaming engine, for the HBM roofline figure
+        os.environ["LDPC_AMD_ENGINE"] = "stream"
+        for timed in (False, True):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dec.decode_batch_dev(d_llr.data_ptr(), F, iters, False, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr(), stream)
+            nl, ms, _ = dec.last_decode_timing()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+        os.environ.pop("LDPC_AMD_ENGINE", None)
+        out["streaming_engine"] = {
+            "value": F * k / (t2 - t1) / 1e9, "unit": "Gbit/s", "ms_per_step": (t2 - t1) * 1e3,
+            "roofline": {"bound": "hbm", "achieved": F * b_frame / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": F * b_frame / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(dec.last_decode_kernel(), F, iters, n),
+                         "kernel": dec.last_decode_kernel(), "launch_ms": ms / max(nl, 1)},
+        }
     if rank == 0:
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(code, args.ebn0, iters, args.cpu_seconds)
