@@ -60,7 +60,7 @@ extern "C" {
 #define LDPC_AMD_CH_AWGN 2     /* BPSK + AWGN at Eb/N0 dB (not in the reference) */
 
 /* layout of the counter vector of ldpc_amd_simulate / ldpc_amd_count_errors_dev:
- * the statistics of LDPC_GallagerIntStreamSimu.java:136-183 for the all-zero codeword */
+ * the statistics of LDPC_GallagerIntStreamSimu.java:136-183 */
 #define LDPC_AMD_CNT_FRAMES 0
 #define LDPC_AMD_CNT_FRAME_ERRORS 1      /* !Arrays.equals(c, decodedC), :136 */
 #define LDPC_AMD_CNT_INFO_BIT_ERRORS 2   /* residualsErrorInfoBits, :156-161 */
@@ -141,27 +141,47 @@ int ldpc_amd_decode_bsc_batch_dev(ldpc_amd_ctx* ctx, const uint8_t* d_r, int64_t
                                   void* stream);
 
 /*
- * On-device channel for the all-zero codeword, frames first_frame .. first_frame+frames-1.
+ * Generator matrix for random codewords.  G is [k][n] bytes (0/1, host), normally the
+ * systematic matrix of TissueEncoder.encodeG (TissueEncoder.java:7-59); the library keeps a
+ * bit-packed copy on the device.  k = 0 or G = NULL clears it, and the transmitted word is
+ * again the all-zero word.  Replaces the per-frame "c = GenerateC.geneC(encodedG)" of
+ * LDPC_GallagerIntStreamSimu.java:115 together with ldpc_amd_gen_codewords_dev.
+ */
+int ldpc_amd_set_generator(ldpc_amd_ctx* ctx, int32_t k, const uint8_t* G);
+
+/*
+ * d_cw[f][j] = (u_f * G)[j] mod 2 for frames first_frame .. first_frame+frames-1
+ * (GenerateC.java:5-27).  Message bit i of frame f is bit (i mod 128) of the Philox4x32-10
+ * block with counter (f, i / 128, stream 2) under `seed`; GenerateC's own Math.random() is
+ * unseeded.  Without a generator matrix d_cw is filled with zeros.
+ */
+int ldpc_amd_gen_codewords_dev(ldpc_amd_ctx* ctx, uint64_t seed, int64_t first_frame, int64_t frames,
+                               uint8_t* d_cw, void* stream);
+
+/*
+ * On-device channel, frames first_frame .. first_frame+frames-1.  d_cw is the transmitted
+ * word per frame ([frames][n] uint8, device) or NULL for the all-zero word.
  * The generator is Philox4x32-10 keyed by `seed` with counter (frame, position/4, stream),
  * so a frame's noise does not depend on how frames are split over calls or GPUs.
  * Replaces Channel.GenerateR / GenerateRBefore (Channel.java:5-17, :28-39), whose
  * java.util.Random is unseeded.
- *   gen_bsc_dev : d_r   [frames][n] uint8, flip iff u32 < floor(e * 2^32)
- *   gen_awgn_dev: d_llr [frames][n] float, 2*y/sigma^2 with y = 1 + sigma*N(0,1),
+ *   gen_bsc_dev : d_r   [frames][n] uint8, c[j] flipped iff u32 < floor(e * 2^32)
+ *   gen_awgn_dev: d_llr [frames][n] float, 2*y/sigma^2 with y = (1 - 2 c[j]) + sigma*N(0,1),
  *                 sigma^2 = 1 / (2 * ((n-m)/n) * 10^(ebn0_db/10))
  */
 int ldpc_amd_gen_bsc_dev(ldpc_amd_ctx* ctx, int32_t channel, double e, uint64_t seed, int64_t first_frame,
-                         int64_t frames, uint8_t* d_r, void* stream);
+                         int64_t frames, const uint8_t* d_cw, uint8_t* d_r, void* stream);
 int ldpc_amd_gen_awgn_llr_dev(ldpc_amd_ctx* ctx, double ebn0_db, uint64_t seed, int64_t first_frame,
-                              int64_t frames, float* d_llr, void* stream);
+                              int64_t frames, const uint8_t* d_cw, float* d_llr, void* stream);
 
 /*
- * Accumulate the statistics of LDPC_GallagerIntStreamSimu.java:136-183 (all-zero codeword)
- * into d_counters[LDPC_AMD_CNT_FIXED + max_iters] (uint64, device).  d_rx_hard is the
- * channel's hard decision per position ([frames][n] uint8); it may be NULL, then the
- * miscorrected / channel-error counters are left untouched.
+ * Accumulate the statistics of LDPC_GallagerIntStreamSimu.java:136-183 into
+ * d_counters[LDPC_AMD_CNT_FIXED + max_iters] (uint64, device).  d_cw is the transmitted
+ * word per frame or NULL for the all-zero word.  d_rx_hard is the channel's hard decision
+ * per position ([frames][n] uint8); it may be NULL, then the miscorrected / channel-error
+ * counters are left untouched.
  */
-int ldpc_amd_count_errors_dev(ldpc_amd_ctx* ctx, int64_t frames, const uint8_t* d_hard,
+int ldpc_amd_count_errors_dev(ldpc_amd_ctx* ctx, int64_t frames, const uint8_t* d_hard, const uint8_t* d_cw,
                               const uint8_t* d_rx_hard, const int32_t* d_iters,
                               const int32_t* d_syndrome_weight, int32_t max_iters, uint64_t* d_counters,
                               void* stream);

@@ -3,9 +3,10 @@
 capi           ctypes binding of the C ABI (include/ldpc_amd.h -> libldpc_amd.so)
 log_decoder    LogDecoder / LogDecoderBefore / MinSumDecoder with the reference's signature
 codes          seeded parity-check matrix builders
+encoder        generator matrix, systematic form, column-permuted H (the reference's encoder chain)
 check_matrix_io  the reference's H text format
 sim            frame sharding over GPUs and the counter all-reduce
 """
-from . import capi, check_matrix_io, codes, sim  # noqa: F401
+from . import capi, check_matrix_io, codes, encoder, sim  # noqa: F401
 from .capi import Decoder, LdpcError  # noqa: F401
 from .log_decoder import DecodeResult, LogDecoder, LogDecoderBefore, MinSumDecoder  # noqa: F401

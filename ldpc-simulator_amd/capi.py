@@ -38,9 +38,11 @@ SIGNATURES = {
     "ldpc_amd_decode_batch_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ldpc_amd_decode_bsc_batch": (C.c_int, [_vp, _vp, _i64, _f64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ldpc_amd_decode_bsc_batch_dev": (C.c_int, [_vp, _vp, _i64, _f64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "ldpc_amd_gen_bsc_dev": (C.c_int, [_vp, _i32, _f64, _u64, _i64, _i64, _vp, _vp]),
-    "ldpc_amd_gen_awgn_llr_dev": (C.c_int, [_vp, _f64, _u64, _i64, _i64, _vp, _vp]),
-    "ldpc_amd_count_errors_dev": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "ldpc_amd_set_generator": (C.c_int, [_vp, _i32, _vp]),
+    "ldpc_amd_gen_codewords_dev": (C.c_int, [_vp, _u64, _i64, _i64, _vp, _vp]),
+    "ldpc_amd_gen_bsc_dev": (C.c_int, [_vp, _i32, _f64, _u64, _i64, _i64, _vp, _vp, _vp]),
+    "ldpc_amd_gen_awgn_llr_dev": (C.c_int, [_vp, _f64, _u64, _i64, _i64, _vp, _vp, _vp]),
+    "ldpc_amd_count_errors_dev": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "ldpc_amd_simulate": (C.c_int, [_vp, _i32, _f64, _u64, _i64, _i64, _i32, _i32, _vp]),
     "ldpc_amd_last_decode_timing": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ldpc_amd_last_decode_kernel": (C.c_char_p, [_vp]),
@@ -157,6 +159,17 @@ class Decoder:
     def set_workspace_limit(self, nbytes):
         self._check(self._lib.ldpc_amd_set_workspace_limit(self._h, int(nbytes)))
 
+    def set_generator(self, G):
+        """G [k][n] 0/1 (e.g. TissueEncoder.encodeG's matrix): simulate() and gen_codewords_dev() then
+        send random codewords u*G (LDPC_GallagerIntStreamSimu.java:115); None goes back to the all-zero word."""
+        if G is None:
+            self._check(self._lib.ldpc_amd_set_generator(self._h, 0, None))
+            return
+        G = np.ascontiguousarray(G, dtype=np.uint8)
+        if G.ndim != 2 or G.shape[1] != self.n:
+            raise ValueError("G must be [k][n]")
+        self._check(self._lib.ldpc_amd_set_generator(self._h, G.shape[0], _np_ptr(G)))
+
     # ---- host-buffer entry points ------------------------------------------------------
     def decode_batch(self, llr, max_iters, early_term=True):
         llr = np.ascontiguousarray(llr, dtype=np.float32)
@@ -202,17 +215,23 @@ class Decoder:
                                                             int(max_iters), int(bool(early_term)), d_hard,
                                                             d_iters or None, d_synd or None, stream or None))
 
-    def gen_bsc_dev(self, channel, e, seed, first_frame, frames, d_r, stream=0):
+    # d_cw: the transmitted words [frames][n] uint8 on the device, 0 = the all-zero word
+    def gen_codewords_dev(self, seed, first_frame, frames, d_cw, stream=0):
+        self._check(self._lib.ldpc_amd_gen_codewords_dev(self._h, int(seed), int(first_frame), int(frames), d_cw,
+                                                         stream or None))
+
+    def gen_bsc_dev(self, channel, e, seed, first_frame, frames, d_r, stream=0, d_cw=0):
         self._check(self._lib.ldpc_amd_gen_bsc_dev(self._h, int(channel), float(e), int(seed), int(first_frame),
-                                                   int(frames), d_r, stream or None))
+                                                   int(frames), d_cw or None, d_r, stream or None))
 
-    def gen_awgn_llr_dev(self, ebn0_db, seed, first_frame, frames, d_llr, stream=0):
+    def gen_awgn_llr_dev(self, ebn0_db, seed, first_frame, frames, d_llr, stream=0, d_cw=0):
         self._check(self._lib.ldpc_amd_gen_awgn_llr_dev(self._h, float(ebn0_db), int(seed), int(first_frame),
-                                                        int(frames), d_llr, stream or None))
+                                                        int(frames), d_cw or None, d_llr, stream or None))
 
-    def count_errors_dev(self, frames, d_hard, d_rx_hard, d_iters, d_synd, max_iters, d_counters, stream=0):
-        self._check(self._lib.ldpc_amd_count_errors_dev(self._h, int(frames), d_hard, d_rx_hard or None, d_iters,
-                                                        d_synd, int(max_iters), d_counters, stream or None))
+    def count_errors_dev(self, frames, d_hard, d_rx_hard, d_iters, d_synd, max_iters, d_counters, stream=0, d_cw=0):
+        self._check(self._lib.ldpc_amd_count_errors_dev(self._h, int(frames), d_hard, d_cw or None,
+                                                        d_rx_hard or None, d_iters, d_synd, int(max_iters),
+                                                        d_counters, stream or None))
 
     def last_decode_kernel(self):
         return (self._lib.ldpc_amd_last_decode_kernel(self._h) or b"").decode()

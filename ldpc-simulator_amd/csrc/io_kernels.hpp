@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(256) unpack_hard_kernel(const uint32_t* ws_bit
 // Channel.java:5-17 / :28-39: "random.nextDouble() < e" becomes u32 < floor(e * 2^32) on one
 // Philox word per position; positions >= flip_end are copied unchanged (error-free parity part).
 __global__ void __launch_bounds__(256) gen_bsc_kernel(int n, int flip_end, uint32_t thr, uint64_t seed,
-                                                      long long first_frame, long long frames, uint8_t* r) {
+                                                      long long first_frame, long long frames, const uint8_t* cw,
+                                                      uint8_t* r) {
     const int n4 = (n + 3) >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long f = idx / n4;
@@ -93,7 +94,10 @@ __global__ void __launch_bounds__(256) gen_bsc_kernel(int n, int flip_end, uint3
     const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
     uint8_t b[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) b[k] = (j + k < flip_end && xs[k] < thr) ? 1 : 0;
+    for (int k = 0; k < 4; ++k) {
+        b[k] = (j + k < flip_end && xs[k] < thr) ? 1 : 0;
+        if (cw && j + k < n) b[k] ^= cw[f * n + j + k];  // r = c with flips (Channel.java:9-13); null = all-zero word
+    }
     uint8_t* o = r + f * n + j;
     if ((n & 3) == 0) {
         *reinterpret_cast<uchar4*>(o) = make_uchar4(b[0], b[1], b[2], b[3]);
@@ -105,7 +109,7 @@ __global__ void __launch_bounds__(256) gen_bsc_kernel(int n, int flip_end, uint3
 // BPSK over AWGN, all-zero codeword (+1 sent): llr = 2*y/sigma^2 = a + b*z, a = 2/sigma^2,
 // b = 2/sigma, z ~ N(0,1) by Box-Muller on two Philox words per pair of positions.
 __global__ void __launch_bounds__(256) gen_awgn_kernel(int n, float a, float b, uint64_t seed, long long first_frame,
-                                                       long long frames, float* llr) {
+                                                       long long frames, const uint8_t* cw, float* llr) {
     const int n4 = (n + 3) >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long f = idx / n4;
@@ -124,14 +128,63 @@ __global__ void __launch_bounds__(256) gen_awgn_kernel(int n, float a, float b, 
         z[2 * h] = rad * cosf(th);
         z[2 * h + 1] = rad * sinf(th);
     }
+    // bit 0 is sent as +1, bit 1 as -1: llr = 2 y / sigma^2 with y = (1 - 2c) + sigma z
     float v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = a + b * z[k];
+    for (int k = 0; k < 4; ++k) {
+        const float sa = (cw && j + k < n && cw[f * n + j + k]) ? -a : a;
+        v[k] = sa + b * z[k];
+    }
     float* o = llr + f * n + j;
     if ((n & 3) == 0) {
         *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
         for (int k = 0; k < 4 && j + k < n; ++k) o[k] = v[k];
+    }
+}
+
+// ---- source: random codewords u * G (GenerateC.java:12-24) --------------------------------------------
+// Gp[k][nw]: rows of the generator matrix packed 32 columns per word.  Message bit i of a frame is bit
+// (i & 127) of the Philox block (frame, i >> 7, stream 2).  A block encodes 8 frames at once so that
+// every word of G it reads serves 8 frames.
+__global__ void __launch_bounds__(256) gen_codewords_kernel(int n, int nw, int k, const uint32_t* Gp, uint64_t seed,
+                                                            long long first_frame, long long frames, uint8_t* cw) {
+    extern __shared__ uint32_t ubits[];  // [8][kw] message bits of the block's frames
+    const int kw = (k + 31) >> 5;
+    const long long f0 = (long long)blockIdx.x * 8;
+    for (int idx = threadIdx.x; idx < 8 * ((k + 127) >> 7); idx += blockDim.x) {
+        const int fr = idx / ((k + 127) >> 7), g = idx % ((k + 127) >> 7);
+        const u32x4 x = frame_block(seed, (uint64_t)(first_frame + f0 + fr), (uint32_t)g, 2u);
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+        for (int q = 0; q < 4; ++q)
+            if (4 * g + q < kw) ubits[fr * kw + 4 * g + q] = xs[q];
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < nw; w += blockDim.x) {
+        uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < k; ++i) {
+            const uint32_t g = Gp[(long long)i * nw + w];
+#pragma unroll
+            for (int fr = 0; fr < 8; ++fr)
+                acc[fr] ^= ((ubits[fr * kw + (i >> 5)] >> (i & 31)) & 1u) ? g : 0u;
+        }
+        for (int fr = 0; fr < 8; ++fr) {
+            const long long f = f0 + fr;
+            if (f >= frames) break;
+            uint8_t* o = cw + f * n + 32 * w;
+            if ((n & 31) == 0) {  // 32 bytes, 16-byte aligned: bit b of the word -> byte b
+                uint32_t q[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const uint32_t nib = (acc[fr] >> (4 * b)) & 15u;
+                    q[b] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+                }
+                reinterpret_cast<uint4*>(o)[0] = make_uint4(q[0], q[1], q[2], q[3]);
+                reinterpret_cast<uint4*>(o)[1] = make_uint4(q[4], q[5], q[6], q[7]);
+            } else {
+                for (int b = 0; b < 32 && 32 * w + b < n; ++b) o[b] = (uint8_t)((acc[fr] >> b) & 1u);
+            }
+        }
     }
 }
 
@@ -149,8 +202,9 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 }
 
 template <class Rx, bool HAS_RX>
-__global__ void __launch_bounds__(256) count_errors_kernel(int n, int k_info, long long frames, const uint8_t* hard, Rx rx,
-                                                           const int32_t* iters, const int32_t* synd, int max_iters,
+__global__ void __launch_bounds__(256) count_errors_kernel(int n, int k_info, long long frames, const uint8_t* hard,
+                                                           const uint8_t* cw, Rx rx, const int32_t* iters,
+                                                           const int32_t* synd, int max_iters,
                                                            unsigned long long* counters) {
     extern __shared__ unsigned long long acc[];  // 16 + max_iters
     const int nc = 16 + max_iters;
@@ -164,11 +218,12 @@ __global__ void __launch_bounds__(256) count_errors_kernel(int n, int k_info, lo
         unsigned info = 0, chk = 0, mis = 0, ch = 0;
         const uint8_t* d = hard + f * n;
         for (int j = lane; j < n; j += 64) {
-            const unsigned dj = d[j] != 0;
+            const unsigned cj = cw ? (cw[f * n + j] != 0) : 0u;  // transmitted bit; null = all-zero word
+            const unsigned dj = (unsigned)(d[j] != 0) ^ cj;       // decoded bit differs from it
             if (j < k_info) {
                 info += dj;
                 if (HAS_RX) {
-                    const unsigned rj = (unsigned)rx(f * n + j);
+                    const unsigned rj = (unsigned)rx(f * n + j) ^ cj;  // channel error on this bit
                     ch += rj;
                     mis += (rj == 0u && dj) ? 1u : 0u;
                 }

@@ -43,6 +43,11 @@ struct ldpc_amd_ctx {
     unsigned long long* d_counters = nullptr;
     size_t counters_len = 0;
     // tables of the frame-resident engine (built on first use, see build_resident_tables)
+    // generator matrix for random codewords: k rows packed 32 columns per word (null = all-zero word)
+    int gen_k = 0;
+    uint32_t* d_gen = nullptr;
+    void* stage_cw = nullptr;
+    size_t stage_cw_bytes = 0;
     int res_nt = 0;
     int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E] | edge_slot[E] | edge_pos[E]
     double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
@@ -478,7 +483,8 @@ uint32_t bsc_threshold(double e) {
     return (t >= 4294967295.0) ? 4294967295u : (uint32_t)t;
 }
 
-int count_launch(ldpc_amd_ctx* c, long long frames, const uint8_t* d_hard, const uint8_t* d_rx, const float* d_rx_llr,
+int count_launch(ldpc_amd_ctx* c, long long frames, const uint8_t* d_hard, const uint8_t* d_cw, const uint8_t* d_rx,
+                 const float* d_rx_llr,
                  const int32_t* d_iters, const int32_t* d_synd, int max_iters, unsigned long long* d_counters,
                  hipStream_t s) {
     if (frames <= 0) return LDPC_AMD_OK;
@@ -487,33 +493,47 @@ int count_launch(ldpc_amd_ctx* c, long long frames, const uint8_t* d_hard, const
     const int k = c->n - c->m;
     if (d_rx) {
         hipLaunchKernelGGL((count_errors_kernel<RxBytes, true>), grid, block, sh, s, c->n, k, frames, d_hard,
-                           RxBytes{d_rx}, d_iters, d_synd, max_iters, d_counters);
+                           d_cw, RxBytes{d_rx}, d_iters, d_synd, max_iters, d_counters);
     } else if (d_rx_llr) {
         hipLaunchKernelGGL((count_errors_kernel<RxLlrSign, true>), grid, block, sh, s, c->n, k, frames, d_hard,
-                           RxLlrSign{d_rx_llr}, d_iters, d_synd, max_iters, d_counters);
+                           d_cw, RxLlrSign{d_rx_llr}, d_iters, d_synd, max_iters, d_counters);
     } else {
-        hipLaunchKernelGGL((count_errors_kernel<RxNone, false>), grid, block, sh, s, c->n, k, frames, d_hard, RxNone{},
-                           d_iters, d_synd, max_iters, d_counters);
+        hipLaunchKernelGGL((count_errors_kernel<RxNone, false>), grid, block, sh, s, c->n, k, frames, d_hard, d_cw,
+                           RxNone{}, d_iters, d_synd, max_iters, d_counters);
     }
     LDPC_HIP(c, hipGetLastError());
     return LDPC_AMD_OK;
 }
 
+int gen_codewords(ldpc_amd_ctx* c, uint64_t seed, long long first_frame, long long frames, uint8_t* d_cw,
+                  hipStream_t s) {
+    if (frames <= 0) return LDPC_AMD_OK;
+    if (!c->d_gen) {  // no generator matrix: the all-zero codeword
+        LDPC_HIP(c, hipMemsetAsync(d_cw, 0, (size_t)frames * c->n, s));
+        return LDPC_AMD_OK;
+    }
+    const int kw = (c->gen_k + 31) / 32;
+    hipLaunchKernelGGL(gen_codewords_kernel, dim3((unsigned)((frames + 7) / 8)), dim3(256), (size_t)8 * kw * 4, s, c->n,
+                       c->nw, c->gen_k, c->d_gen, seed, first_frame, frames, d_cw);
+    LDPC_HIP(c, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
 int gen_bsc(ldpc_amd_ctx* c, int channel, double e, uint64_t seed, long long first_frame, long long frames,
-            uint8_t* d_r, hipStream_t s) {
+            const uint8_t* d_cw, uint8_t* d_r, hipStream_t s) {
     if (channel != LDPC_AMD_CH_BSC_INFO && channel != LDPC_AMD_CH_BSC_ALL)
         return fail(c, LDPC_AMD_EINVAL, "gen_bsc: channel must be a BSC channel");
     if (frames <= 0) return LDPC_AMD_OK;
     const int flip_end = (channel == LDPC_AMD_CH_BSC_INFO) ? (c->n - c->m) : c->n;
     const long long threads = frames * ((c->n + 3) / 4);
     hipLaunchKernelGGL(gen_bsc_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, c->n, flip_end,
-                       bsc_threshold(e), seed, first_frame, frames, d_r);
+                       bsc_threshold(e), seed, first_frame, frames, d_cw, d_r);
     LDPC_HIP(c, hipGetLastError());
     return LDPC_AMD_OK;
 }
 
-int gen_awgn(ldpc_amd_ctx* c, double ebn0_db, uint64_t seed, long long first_frame, long long frames, float* d_llr,
-             hipStream_t s) {
+int gen_awgn(ldpc_amd_ctx* c, double ebn0_db, uint64_t seed, long long first_frame, long long frames,
+             const uint8_t* d_cw, float* d_llr, hipStream_t s) {
     if (frames <= 0) return LDPC_AMD_OK;
     if (c->n <= c->m) return fail(c, LDPC_AMD_EINVAL, "gen_awgn: code rate (n-m)/n must be positive");
     const double rate = (double)(c->n - c->m) / (double)c->n;
@@ -521,7 +541,7 @@ int gen_awgn(ldpc_amd_ctx* c, double ebn0_db, uint64_t seed, long long first_fra
     const float a = (float)(2.0 / sigma2), b = (float)(2.0 / std::sqrt(sigma2));
     const long long threads = frames * ((c->n + 3) / 4);
     hipLaunchKernelGGL(gen_awgn_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, c->n, a, b, seed,
-                       first_frame, frames, d_llr);
+                       first_frame, frames, d_cw, d_llr);
     LDPC_HIP(c, hipGetLastError());
     return LDPC_AMD_OK;
 }
@@ -587,7 +607,7 @@ int ldpc_amd_destroy(ldpc_amd_ctx* c) {
         (void)hipDeviceSynchronize();
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
         void* ptrs[] = {c->d_row_ptr, c->d_edge_col, c->d_col_ptr, c->d_col_edge, c->ws, c->d_res,
-                        c->stage[0],  c->stage[1],   c->stage[2],  c->stage[3],   c->d_counters};
+                        c->stage[0],  c->stage[1],   c->stage[2],  c->stage[3],   c->d_counters, c->d_gen,      c->stage_cw};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -698,33 +718,63 @@ int ldpc_amd_decode_bsc_batch(ldpc_amd_ctx* c, const uint8_t* r, int64_t frames,
     return decode_host(c, r, 1, true, e, llr_mode, frames, max_iters, early_term, hard, iters, synd);
 }
 
+int ldpc_amd_set_generator(ldpc_amd_ctx* c, int32_t k, const uint8_t* G) {
+    if (!c) return LDPC_AMD_EINVAL;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    if (c->d_gen) {
+        LDPC_HIP(c, hipFree(c->d_gen));
+        c->d_gen = nullptr;
+        c->gen_k = 0;
+    }
+    if (k == 0 || !G) return LDPC_AMD_OK;
+    if (k < 0) return fail(c, LDPC_AMD_EINVAL, "set_generator: k must be >= 0");
+    std::vector<uint32_t> packed((size_t)k * c->nw, 0u);
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < c->n; ++j)
+            if (G[(size_t)i * c->n + j] & 1) packed[(size_t)i * c->nw + (j >> 5)] |= 1u << (j & 31);
+    LDPC_HIP(c, hipMalloc((void**)&c->d_gen, packed.size() * sizeof(uint32_t)));
+    LDPC_HIP(c, hipMemcpy(c->d_gen, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->gen_k = k;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_gen_codewords_dev(ldpc_amd_ctx* c, uint64_t seed, int64_t first_frame, int64_t frames, uint8_t* d_cw,
+                               void* stream) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (frames < 0 || (frames > 0 && !d_cw)) return fail(c, LDPC_AMD_EINVAL, "gen_codewords: bad argument");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    return gen_codewords(c, seed, first_frame, frames, d_cw, (hipStream_t)stream);
+}
+
 int ldpc_amd_gen_bsc_dev(ldpc_amd_ctx* c, int32_t channel, double e, uint64_t seed, int64_t first_frame,
-                         int64_t frames, uint8_t* d_r, void* stream) {
+                         int64_t frames, const uint8_t* d_cw, uint8_t* d_r, void* stream) {
     if (!c) return LDPC_AMD_EINVAL;
     if (frames < 0 || (frames > 0 && !d_r)) return fail(c, LDPC_AMD_EINVAL, "gen_bsc: bad argument");
     DeviceGuard guard(c->device);
     if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
-    return gen_bsc(c, channel, e, seed, first_frame, frames, d_r, (hipStream_t)stream);
+    return gen_bsc(c, channel, e, seed, first_frame, frames, d_cw, d_r, (hipStream_t)stream);
 }
 
 int ldpc_amd_gen_awgn_llr_dev(ldpc_amd_ctx* c, double ebn0_db, uint64_t seed, int64_t first_frame, int64_t frames,
-                              float* d_llr, void* stream) {
+                              const uint8_t* d_cw, float* d_llr, void* stream) {
     if (!c) return LDPC_AMD_EINVAL;
     if (frames < 0 || (frames > 0 && !d_llr)) return fail(c, LDPC_AMD_EINVAL, "gen_awgn: bad argument");
     DeviceGuard guard(c->device);
     if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
-    return gen_awgn(c, ebn0_db, seed, first_frame, frames, d_llr, (hipStream_t)stream);
+    return gen_awgn(c, ebn0_db, seed, first_frame, frames, d_cw, d_llr, (hipStream_t)stream);
 }
 
-int ldpc_amd_count_errors_dev(ldpc_amd_ctx* c, int64_t frames, const uint8_t* d_hard, const uint8_t* d_rx_hard,
-                              const int32_t* d_iters, const int32_t* d_synd, int32_t max_iters, uint64_t* d_counters,
+int ldpc_amd_count_errors_dev(ldpc_amd_ctx* c, int64_t frames, const uint8_t* d_hard, const uint8_t* d_cw,
+                              const uint8_t* d_rx_hard, const int32_t* d_iters, const int32_t* d_synd, int32_t max_iters, uint64_t* d_counters,
                               void* stream) {
     if (!c) return LDPC_AMD_EINVAL;
     if (frames < 0 || max_iters < 0 || (frames > 0 && (!d_hard || !d_iters || !d_synd || !d_counters)))
         return fail(c, LDPC_AMD_EINVAL, "count_errors: bad argument");
     DeviceGuard guard(c->device);
     if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
-    return count_launch(c, frames, d_hard, d_rx_hard, nullptr, d_iters, d_synd, max_iters,
+    return count_launch(c, frames, d_hard, d_cw, d_rx_hard, nullptr, d_iters, d_synd, max_iters,
                         (unsigned long long*)d_counters, (hipStream_t)stream);
 }
 
@@ -762,22 +812,32 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
         if (int rc = ensure_stage(c, 2, (size_t)nf * 4)) return rc;
         if (int rc = ensure_stage(c, 3, (size_t)nf * 4)) return rc;
         int rc;
+        const uint8_t* cw = nullptr;  // transmitted words of this chunk; null = the all-zero word
+        if (c->d_gen) {
+            if (c->stage_cw_bytes < (size_t)nf * n) {
+                if (c->stage_cw) LDPC_HIP(c, hipFree(c->stage_cw));
+                c->stage_cw = nullptr;
+                c->stage_cw_bytes = 0;
+                LDPC_HIP(c, hipMalloc(&c->stage_cw, (size_t)nf * n));
+                c->stage_cw_bytes = (size_t)nf * n;
+            }
+            rc = gen_codewords(c, seed, first_frame + f0, nf, (uint8_t*)c->stage_cw, nullptr);
+            if (rc) return rc;
+            cw = (const uint8_t*)c->stage_cw;
+        }
         SrcArgs src{};
         if (awgn) {
-            rc = gen_awgn(c, param, seed, first_frame + f0, nf, (float*)c->stage[0], nullptr);
+            rc = gen_awgn(c, param, seed, first_frame + f0, nf, cw, (float*)c->stage[0], nullptr);
             src = SrcArgs{Src::Float, (const float*)c->stage[0], nullptr, 0.0, 0.0};
         } else {
-            rc = gen_bsc(c, channel, param, seed, first_frame + f0, nf, (uint8_t*)c->stage[0], nullptr);
+            rc = gen_bsc(c, channel, param, seed, first_frame + f0, nf, cw, (uint8_t*)c->stage[0], nullptr);
             src = SrcArgs{Src::Bsc, nullptr, (const uint8_t*)c->stage[0], l0, l1};
         }
         if (rc) return rc;
         rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)c->stage[1], (int32_t*)c->stage[2],
                         (int32_t*)c->stage[3], nullptr);
         if (rc) return rc;
-        if (max_iters == 0) {
-            // nothing ran: the histogram has no bin for 0 iterations, the fixed counters still apply
-        }
-        rc = count_launch(c, nf, (const uint8_t*)c->stage[1], awgn ? nullptr : (const uint8_t*)c->stage[0],
+        rc = count_launch(c, nf, (const uint8_t*)c->stage[1], cw, awgn ? nullptr : (const uint8_t*)c->stage[0],
                           awgn ? (const float*)c->stage[0] : nullptr, (const int32_t*)c->stage[2],
                           (const int32_t*)c->stage[3], max_iters, c->d_counters, nullptr);
         if (rc) return rc;

@@ -415,23 +415,41 @@ static inline uint32_t bsc_threshold(double e) {
     return (t >= 4294967295.0) ? 4294967295u : (uint32_t)t;
 }
 
-/* Channel.java:5-17 (info positions only) / :28-39 (all positions), all-zero codeword.
- * nextDouble() < e becomes u32 < floor(e * 2^32) on one Philox word per position. */
+/* GenerateC.java:5-27: c = u * G over GF(2).  The reference draws u from Math.random();
+ * here message bit i of frame f is bit (i mod 128) of the Philox block (f, i / 128, stream 2).
+ * G is [k][n] bytes; G == NULL gives the all-zero word. */
+void oracle_gen_codewords(int n, int k, const uint8_t* G, uint64_t seed, int64_t first_frame,
+                          int64_t frames, uint8_t* cw) {
+    memset(cw, 0, (size_t)frames * (size_t)n);
+    if (!G) return;
+    for (int64_t f = 0; f < frames; f++) {
+        uint32_t x[4] = {0, 0, 0, 0};
+        for (int i = 0; i < k; i++) {
+            if ((i & 127) == 0) frame_block(seed, (uint64_t)(first_frame + f), (uint32_t)(i >> 7), 2u, x);
+            if ((x[(i & 127) >> 5] >> (i & 31)) & 1u)
+                for (int j = 0; j < n; j++) cw[f * n + j] ^= (uint8_t)(G[(size_t)i * n + j] & 1);
+        }
+    }
+}
+
+/* Channel.java:5-17 (info positions only) / :28-39 (all positions); cw == NULL is the all-zero
+ * word.  nextDouble() < e becomes u32 < floor(e * 2^32) on one Philox word per position. */
 void oracle_gen_bsc(int m, int n, int channel, double e, uint64_t seed, int64_t first_frame,
-                    int64_t frames, uint8_t* r) {
+                    int64_t frames, const uint8_t* cw, uint8_t* r) {
     const uint32_t thr = bsc_threshold(e);
     const int flip_end = (channel == ORACLE_CH_BSC_INFO) ? (n - m) : n;
     for (int64_t f = 0; f < frames; f++) {
         uint32_t x[4];
         for (int j = 0; j < n; j++) {
             if ((j & 3) == 0) frame_block(seed, (uint64_t)(first_frame + f), (uint32_t)(j >> 2), 0u, x);
-            r[f * n + j] = (j < flip_end && x[j & 3] < thr) ? 1 : 0;
+            const uint8_t flip = (j < flip_end && x[j & 3] < thr) ? 1 : 0;
+            r[f * n + j] = (uint8_t)((cw ? (cw[f * n + j] & 1) : 0) ^ flip);
         }
     }
 }
 
 void oracle_gen_awgn_llr(int m, int n, double ebn0_db, uint64_t seed, int64_t first_frame,
-                         int64_t frames, float* llr) {
+                         int64_t frames, const uint8_t* cw, float* llr) {
     const double rate = (double)(n - m) / (double)n;
     const double sigma2 = 1.0 / (2.0 * rate * pow(10.0, ebn0_db / 10.0));
     const float a = (float)(2.0 / sigma2);
@@ -449,26 +467,35 @@ void oracle_gen_awgn_llr(int m, int n, double ebn0_db, uint64_t seed, int64_t fi
                 z[2 * h] = rad * cosf(th);
                 z[2 * h + 1] = rad * sinf(th);
             }
-            for (int t = 0; t < 4 && j0 + t < n; t++) llr[f * n + j0 + t] = a + b * z[t];
+            for (int t = 0; t < 4 && j0 + t < n; t++) {
+                const float sa = (cw && cw[f * n + j0 + t]) ? -a : a; /* bit 1 is sent as -1 */
+                llr[f * n + j0 + t] = sa + b * z[t];
+            }
         }
     }
 }
 
-/* LDPC_GallagerIntStreamSimu.java:136-183 with c = all-zero codeword. */
-void oracle_count_errors(int m, int n, int64_t frames, const uint8_t* hard, const uint8_t* rx_hard,
-                         const int32_t* iters, const int32_t* syndrome_weight, int max_iters,
-                         uint64_t* counters) {
+/* LDPC_GallagerIntStreamSimu.java:136-183; cw == NULL is the all-zero codeword. */
+void oracle_count_errors(int m, int n, int64_t frames, const uint8_t* hard, const uint8_t* cw,
+                         const uint8_t* rx_hard, const int32_t* iters, const int32_t* syndrome_weight,
+                         int max_iters, uint64_t* counters) {
     const int k = n - m;
     for (int64_t f = 0; f < frames; f++) {
         const uint8_t* d = hard + f * n;
         const uint8_t* r = rx_hard + f * n;
         uint64_t info = 0, chk = 0, mis = 0, ch = 0;
-        for (int j = 0; j < k; j++) {
-            info += d[j];
-            if (r[j] == 0 && d[j] != 0) mis++; /* :162-164 */
-            ch += r[j];                          /* Channel.java:18-27 */
+        for (int j = 0; j < n; j++) {
+            const int cj = cw ? (cw[f * n + j] != 0) : 0;
+            const int dj = (d[j] != 0) != cj; /* decodedC[j] != c[j] */
+            const int rj = (r[j] != 0) != cj; /* r[j] != c[j] */
+            if (j < k) {
+                info += (uint64_t)dj;       /* :156-161 */
+                if (!rj && dj) mis++;       /* :162-164 */
+                ch += (uint64_t)rj;         /* Channel.java:18-27 */
+            } else {
+                chk += (uint64_t)dj;        /* :167-172 */
+            }
         }
-        for (int j = (k > 0 ? k : 0); j < n; j++) chk += d[j];
         const int correct = (info + chk) == 0; /* Arrays.equals(c, decodedC), :136 */
         counters[0] += 1;
         if (!correct) counters[1] += 1;
@@ -486,26 +513,28 @@ void oracle_count_errors(int m, int n, int64_t frames, const uint8_t* hard, cons
     }
 }
 
-int oracle_simulate(const oracle_graph* g, int channel, double param, uint64_t seed,
-                    int64_t first_frame, int64_t frames, int max_iters, int early_term,
+int oracle_simulate(const oracle_graph* g, int gen_k, const uint8_t* G, int channel, double param,
+                    uint64_t seed, int64_t first_frame, int64_t frames, int max_iters, int early_term,
                     int cn_rule, uint64_t* counters, int threads) {
     const int m = g->m, n = g->n;
     const int64_t chunk = 256;
     uint8_t* r = (uint8_t*)malloc((size_t)chunk * n);
     uint8_t* hard = (uint8_t*)malloc((size_t)chunk * n);
+    uint8_t* cw = G ? (uint8_t*)malloc((size_t)chunk * n) : NULL;
     float* llr = (float*)malloc((size_t)chunk * n * sizeof(float));
     double* tmp = (double*)malloc((size_t)(n ? n : 1) * sizeof(double));
     int32_t* it = (int32_t*)malloc((size_t)chunk * sizeof(int32_t));
     int32_t* sw = (int32_t*)malloc((size_t)chunk * sizeof(int32_t));
-    if (!r || !hard || !llr || !tmp || !it || !sw) return -2;
+    if (!r || !hard || (G && !cw) || !llr || !tmp || !it || !sw) return -2;
     int rc = 0;
     for (int64_t f0 = 0; f0 < frames && rc == 0; f0 += chunk) {
         const int64_t nf = (frames - f0 < chunk) ? (frames - f0) : chunk;
+        if (G) oracle_gen_codewords(n, gen_k, G, seed, first_frame + f0, nf, cw);
         if (channel == ORACLE_CH_AWGN) {
-            oracle_gen_awgn_llr(m, n, param, seed, first_frame + f0, nf, llr);
+            oracle_gen_awgn_llr(m, n, param, seed, first_frame + f0, nf, cw, llr);
             for (int64_t t = 0; t < nf * n; t++) r[t] = (llr[t] < 0.0f) ? 1 : 0;
         } else {
-            oracle_gen_bsc(m, n, channel, param, seed, first_frame + f0, nf, r);
+            oracle_gen_bsc(m, n, channel, param, seed, first_frame + f0, nf, cw, r);
             const int mode = (channel == ORACLE_CH_BSC_INFO) ? ORACLE_LLR_PARITY_LN1E20 : ORACLE_LLR_UNIFORM;
             for (int64_t f = 0; f < nf; f++) {
                 oracle_bsc_llr(m, n, r + f * n, param, mode, tmp);
@@ -514,8 +543,8 @@ int oracle_simulate(const oracle_graph* g, int channel, double param, uint64_t s
             }
         }
         rc = oracle_decode_llr_batch_f32(g, llr, nf, max_iters, early_term, cn_rule, hard, it, sw, threads);
-        if (rc == 0) oracle_count_errors(m, n, nf, hard, r, it, sw, max_iters, counters);
+        if (rc == 0) oracle_count_errors(m, n, nf, hard, cw, r, it, sw, max_iters, counters);
     }
-    free(r); free(hard); free(llr); free(tmp); free(it); free(sw);
+    free(r); free(hard); free(cw); free(llr); free(tmp); free(it); free(sw);
     return rc;
 }

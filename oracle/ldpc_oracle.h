@@ -76,25 +76,31 @@ int oracle_logdecoder_dense_batch(const int32_t* H, int m, int n, const uint8_t*
 /* Philox4x32-10 (Salmon et al., SC'11), the counter-based generator the device path uses. */
 void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
-/* Received hard words for the all-zero codeword, frames first_frame..first_frame+frames-1.
+/* Random codewords c = u * G (GenerateC.java:5-27); message bit i of frame f is bit (i mod 128)
+ * of the Philox block (f, i / 128, stream 2).  G is [k][n] bytes, NULL = the all-zero word. */
+void oracle_gen_codewords(int n, int k, const uint8_t* G, uint64_t seed, int64_t first_frame,
+                          int64_t frames, uint8_t* cw);
+
+/* Received hard words, frames first_frame..first_frame+frames-1; cw is the transmitted word
+ * per frame ([frames][n]) or NULL for the all-zero word.
  * channel = ORACLE_CH_BSC_INFO flips only j < n-m (Channel.java:8-15), ORACLE_CH_BSC_ALL
  * flips every position (Channel.java:31-37).  r is [frames][n]. */
 void oracle_gen_bsc(int m, int n, int channel, double e, uint64_t seed, int64_t first_frame,
-                    int64_t frames, uint8_t* r);
-/* BPSK/AWGN channel LLRs of the all-zero codeword at Eb/N0 (dB), rate (n-m)/n. llr [frames][n]. */
+                    int64_t frames, const uint8_t* cw, uint8_t* r);
+/* BPSK/AWGN channel LLRs at Eb/N0 (dB), rate (n-m)/n. llr [frames][n]. */
 void oracle_gen_awgn_llr(int m, int n, double ebn0_db, uint64_t seed, int64_t first_frame,
-                         int64_t frames, float* llr);
+                         int64_t frames, const uint8_t* cw, float* llr);
 
-/* Error accounting against the all-zero codeword
+/* Error accounting against the transmitted word (NULL = all-zero)
  * (LDPC_GallagerIntStreamSimu.java:136-183).  counters has 16 + max_iters entries and is
  * ACCUMULATED into.  rx_hard is the channel's hard decision per position. */
-void oracle_count_errors(int m, int n, int64_t frames, const uint8_t* hard, const uint8_t* rx_hard,
-                         const int32_t* iters, const int32_t* syndrome_weight, int max_iters,
-                         uint64_t* counters);
+void oracle_count_errors(int m, int n, int64_t frames, const uint8_t* hard, const uint8_t* cw,
+                         const uint8_t* rx_hard, const int32_t* iters, const int32_t* syndrome_weight,
+                         int max_iters, uint64_t* counters);
 
-/* Whole Monte-Carlo leg on the CPU: generate, decode, count. */
-int oracle_simulate(const oracle_graph* g, int channel, double param, uint64_t seed,
-                    int64_t first_frame, int64_t frames, int max_iters, int early_term,
+/* Whole Monte-Carlo leg on the CPU: generate, decode, count.  G ([gen_k][n] bytes) may be NULL. */
+int oracle_simulate(const oracle_graph* g, int gen_k, const uint8_t* G, int channel, double param,
+                    uint64_t seed, int64_t first_frame, int64_t frames, int max_iters, int early_term,
                     int cn_rule, uint64_t* counters, int threads);
 
 int oracle_max_threads(void);

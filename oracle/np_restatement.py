@@ -123,3 +123,70 @@ def log_decoder(H, r, e, max_l, mode="ln1e20", rule="sum-product"):
     H = np.asarray(H)
     m, n = H.shape
     return decode_llr(H, channel_llr(m, n, r, e, mode), max_l, True, rule)
+
+
+# ---- encoder chain, literal loops (GenerateMatrix.java:37-89, TissueEncoder.java:7-70, GenerateC.java:5-27)
+def generator_matrix_ref(H):
+    H = [[int(v) for v in row] for row in np.asarray(H)]
+    m, n = len(H), len(H[0])
+    A = [[0] * (n + m) for _ in range(n)]
+    for i in range(n):
+        for j in range(m):
+            A[i][j] = H[j][i]
+    for i in range(n):
+        for j in range(m, m + n):
+            A[i][j] = 1 if i + m == j else 0
+    for i in range(m):
+        tempo = [j for j in range(n) if j > i and A[j][i] == 1]
+        if len(tempo) == 0:
+            continue
+        if A[i][i] != 1:
+            A[i], A[tempo[0]] = A[tempo[0]], A[i]
+        for j in tempo:
+            if A[j][i] == 1:
+                for k in range(n + m):
+                    if A[i][k] == 1 and A[j][k] == 0:
+                        A[j][k] = 1
+                        continue
+                    if A[i][k] == 1 and A[j][k] == 1:
+                        A[j][k] = 0
+    return np.array([[A[m + i][m + j] for j in range(n)] for i in range(n - m)], np.int32)
+
+
+def encode_g_ref(G):
+    E = [[int(v) for v in row] for row in np.asarray(G)]
+    k, n = len(E), len(E[0])
+    column = []
+    for i in range(k):
+        if E[i][i] != 1:
+            col = None
+            for jc in range(n):
+                if E[i][jc] == 1:
+                    col = jc
+                    column += [i, jc]
+                    break
+            for r in range(k):
+                E[r][col], E[r][i] = E[r][i], E[r][col]
+        rows = [jr for jr in range(k) if E[jr][i] == 1 and jr != i]
+        for jr in rows:
+            for a in range(n):
+                if E[i][a] == 1 and E[jr][a] == 1:
+                    E[jr][a] = 0
+                    continue
+                if E[i][a] == 1 and E[jr][a] == 0:
+                    E[jr][a] = 1
+    return np.array(E, np.int32), column
+
+
+def encode_h_ref(H, column):
+    E = [[int(v) for v in row] for row in np.asarray(H)]
+    for i in range(len(column) // 2):
+        for j in range(len(E)):
+            E[j][column[2 * i]], E[j][column[2 * i + 1]] = E[j][column[2 * i + 1]], E[j][column[2 * i]]
+    return np.array(E, np.int32)
+
+
+def gene_c_ref(encodedG, message):
+    """GenerateC.geneC with the random message supplied by the caller."""
+    G = np.asarray(encodedG, dtype=np.int64)
+    return (np.asarray(message, dtype=np.int64) @ G % 2).astype(np.int32)

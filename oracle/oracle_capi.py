@@ -41,10 +41,11 @@ def _load():
     lib.oracle_logdecoder_dense.argtypes = [vp, i32, i32, vp, f64, i32, i32, i32, vp, vp, vp]
     lib.oracle_logdecoder_dense_batch.argtypes = [vp, i32, i32, vp, i64, f64, i32, i32, vp, vp, vp, i32]
     lib.oracle_philox4x32_10.argtypes = [vp, vp, vp]
-    lib.oracle_gen_bsc.argtypes = [i32, i32, i32, f64, u64, i64, i64, vp]
-    lib.oracle_gen_awgn_llr.argtypes = [i32, i32, f64, u64, i64, i64, vp]
-    lib.oracle_count_errors.argtypes = [i32, i32, i64, vp, vp, vp, vp, i32, vp]
-    lib.oracle_simulate.argtypes = [vp, i32, f64, u64, i64, i64, i32, i32, i32, vp, i32]
+    lib.oracle_gen_codewords.argtypes = [i32, i32, vp, u64, i64, i64, vp]
+    lib.oracle_gen_bsc.argtypes = [i32, i32, i32, f64, u64, i64, i64, vp, vp]
+    lib.oracle_gen_awgn_llr.argtypes = [i32, i32, f64, u64, i64, i64, vp, vp]
+    lib.oracle_count_errors.argtypes = [i32, i32, i64, vp, vp, vp, vp, vp, i32, vp]
+    lib.oracle_simulate.argtypes = [vp, i32, vp, i32, f64, u64, i64, i64, i32, i32, i32, vp, i32]
     lib.oracle_max_threads.restype = i32
     return lib
 
@@ -130,9 +131,13 @@ class Graph:
         return hard, it, sw
 
     def simulate(self, channel, param, seed, first_frame, frames, max_iters, early_term=True,
-                 cn_rule=CN_SUMPRODUCT, threads=None):
+                 cn_rule=CN_SUMPRODUCT, threads=None, G=None):
         counters = np.zeros(NUM_FIXED_COUNTERS + int(max_iters), np.uint64)
-        rc = lib().oracle_simulate(self._h, int(channel), float(param), int(seed), int(first_frame), int(frames),
+        if G is not None:
+            G = np.ascontiguousarray(G, dtype=np.uint8)
+            assert G.ndim == 2 and G.shape[1] == self.n
+        rc = lib().oracle_simulate(self._h, 0 if G is None else G.shape[0], None if G is None else _p(G),
+                                   int(channel), float(param), int(seed), int(first_frame), int(frames),
                                    int(max_iters), int(bool(early_term)), int(cn_rule), _p(counters),
                                    int(threads or max_threads()))
         if rc != 0:
@@ -184,25 +189,45 @@ def philox4x32_10(ctr, key):
     return out
 
 
-def gen_bsc(m, n, channel, e, seed, first_frame, frames):
+def _cw(cw, frames, n):
+    if cw is None:
+        return None, None
+    cw = np.ascontiguousarray(cw, dtype=np.uint8)
+    assert cw.shape == (frames, n)
+    return cw, _p(cw)
+
+
+def gen_codewords(G, seed, first_frame, frames):
+    """c = u * G for Philox-drawn messages u (GenerateC.java:5-27); G None -> zeros (needs n: pass an (0, n) array)."""
+    G = np.ascontiguousarray(G, dtype=np.uint8)
+    k, n = G.shape
+    cw = np.zeros((frames, n), np.uint8)
+    lib().oracle_gen_codewords(int(n), int(k), _p(G) if k else None, int(seed), int(first_frame), int(frames), _p(cw))
+    return cw
+
+
+def gen_bsc(m, n, channel, e, seed, first_frame, frames, cw=None):
     r = np.zeros((frames, n), np.uint8)
-    lib().oracle_gen_bsc(int(m), int(n), int(channel), float(e), int(seed), int(first_frame), int(frames), _p(r))
+    cw, pc = _cw(cw, frames, n)
+    lib().oracle_gen_bsc(int(m), int(n), int(channel), float(e), int(seed), int(first_frame), int(frames), pc, _p(r))
     return r
 
 
-def gen_awgn_llr(m, n, ebn0_db, seed, first_frame, frames):
+def gen_awgn_llr(m, n, ebn0_db, seed, first_frame, frames, cw=None):
     llr = np.zeros((frames, n), np.float32)
-    lib().oracle_gen_awgn_llr(int(m), int(n), float(ebn0_db), int(seed), int(first_frame), int(frames), _p(llr))
+    cw, pc = _cw(cw, frames, n)
+    lib().oracle_gen_awgn_llr(int(m), int(n), float(ebn0_db), int(seed), int(first_frame), int(frames), pc, _p(llr))
     return llr
 
 
-def count_errors(m, n, hard, rx_hard, iters, synd, max_iters, counters=None):
+def count_errors(m, n, hard, rx_hard, iters, synd, max_iters, counters=None, cw=None):
     hard = np.ascontiguousarray(hard, dtype=np.uint8)
     rx_hard = np.ascontiguousarray(rx_hard, dtype=np.uint8)
     iters = np.ascontiguousarray(iters, dtype=np.int32)
     synd = np.ascontiguousarray(synd, dtype=np.int32)
+    cw, pc = _cw(cw, hard.shape[0], n)
     if counters is None:
         counters = np.zeros(NUM_FIXED_COUNTERS + int(max_iters), np.uint64)
-    lib().oracle_count_errors(int(m), int(n), hard.shape[0], _p(hard), _p(rx_hard), _p(iters), _p(synd),
+    lib().oracle_count_errors(int(m), int(n), hard.shape[0], _p(hard), pc, _p(rx_hard), _p(iters), _p(synd),
                               int(max_iters), _p(counters))
     return counters

@@ -1,0 +1,106 @@
+"""Device side of the encoder chain: random codewords u*G (GenerateC.java:5-27), the channel and the
+accounting around a transmitted word (LDPC_GallagerIntStreamSimu.java:115-183), against the CPU checker."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sys_code(pkg, oracle):
+    """The reference's default shape in systematic form: Gallager (8,2) n=1024 -> encodedH, encodedG."""
+    m, n, rows, cols = pkg.codes.gallager(1024, 8, 2, seed=1)
+    H = pkg.check_matrix_io.to_dense(m, n, rows, cols)
+    eh, eg = pkg.encoder.systematic_pair(H)
+    r, c = np.nonzero(eh)
+    return dict(m=m, n=n, eh=eh, eg=eg, dec=pkg.Decoder(m, n, r, c), g=oracle.Graph(m, n, r, c))
+
+
+def test_codewords_bit_exact(sys_code, oracle):
+    import torch
+    c = sys_code
+    dec, n = c["dec"], c["n"]
+    dec.set_generator(c["eg"])
+    for first, F in ((0, 8), (123456789012, 301), (7, 1)):      # ragged: not a multiple of the 8 frames a block encodes
+        d_cw = torch.full((F, n), 9, dtype=torch.uint8, device="cuda")
+        dec.gen_codewords_dev(42, first, F, d_cw.data_ptr())
+        torch.cuda.synchronize()
+        got = d_cw.cpu().numpy()
+        assert (got == oracle.gen_codewords(c["eg"], 42, first, F)).all()
+        assert not ((got.astype(np.int64) @ c["eh"].T) % 2).any()
+    dec.gen_codewords_dev(42, 0, 0, 0)                           # empty batch
+    dec.set_generator(None)
+    d_cw = torch.full((5, n), 9, dtype=torch.uint8, device="cuda")
+    dec.gen_codewords_dev(42, 0, 5, d_cw.data_ptr())
+    torch.cuda.synchronize()
+    assert not d_cw.any()                                        # no generator: the all-zero word
+
+
+def test_codewords_odd_length(pkg, oracle):
+    """n not a multiple of 32 and k not a multiple of 32 or 128: the byte-wise tail paths."""
+    import torch
+    rng = np.random.default_rng(5)
+    m, n, k = 30, 75, 45
+    G = rng.integers(0, 2, (k, n)).astype(np.uint8)
+    rows, cols = np.nonzero(rng.random((m, n)) < 0.1)
+    dec = pkg.Decoder(m, n, rows, cols)
+    dec.set_generator(G)
+    d_cw = torch.empty((19, n), dtype=torch.uint8, device="cuda")
+    dec.gen_codewords_dev(3, 100, 19, d_cw.data_ptr())
+    torch.cuda.synchronize()
+    assert (d_cw.cpu().numpy() == oracle.gen_codewords(G, 3, 100, 19)).all()
+
+
+def test_channel_and_counts_with_codewords(sys_code, oracle):
+    import torch
+    c = sys_code
+    dec, m, n = c["dec"], c["m"], c["n"]
+    F, L = 400, 30
+    dec.set_generator(c["eg"])
+    d_cw = torch.empty((F, n), dtype=torch.uint8, device="cuda")
+    dec.gen_codewords_dev(1, 50, F, d_cw.data_ptr())
+    cw = oracle.gen_codewords(c["eg"], 1, 50, F)
+    for ch in (oracle.CH_BSC_INFO, oracle.CH_BSC_ALL):
+        d_r = torch.empty((F, n), dtype=torch.uint8, device="cuda")
+        dec.gen_bsc_dev(ch, 0.03, 8, 50, F, d_r.data_ptr(), d_cw=d_cw.data_ptr())
+        torch.cuda.synchronize()
+        r = oracle.gen_bsc(m, n, ch, 0.03, 8, 50, F, cw=cw)
+        assert (d_r.cpu().numpy() == r).all()
+    d_llr = torch.empty((F, n), dtype=torch.float32, device="cuda")
+    dec.gen_awgn_llr_dev(2.0, 8, 50, F, d_llr.data_ptr(), d_cw=d_cw.data_ptr())
+    torch.cuda.synchronize()
+    assert np.allclose(d_llr.cpu().numpy(), oracle.gen_awgn_llr(m, n, 2.0, 8, 50, F, cw=cw), rtol=2e-5, atol=2e-5)
+    # decode the BSC_ALL words and count against the transmitted words, on the device and in the checker
+    d_hard = torch.empty((F, n), dtype=torch.uint8, device="cuda")
+    d_it = torch.empty(F, dtype=torch.int32, device="cuda")
+    d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
+    dec.decode_bsc_batch_dev(d_r.data_ptr(), F, 0.03, oracle.LLR_UNIFORM, L, True, d_hard.data_ptr(), d_it.data_ptr(),
+                             d_sw.data_ptr())
+    d_cnt = torch.zeros(16 + L, dtype=torch.int64, device="cuda")
+    dec.count_errors_dev(F, d_hard.data_ptr(), d_r.data_ptr(), d_it.data_ptr(), d_sw.data_ptr(), L, d_cnt.data_ptr(),
+                         d_cw=d_cw.data_ptr())
+    torch.cuda.synchronize()
+    want = oracle.count_errors(m, n, d_hard.cpu().numpy(), r, d_it.cpu().numpy(), d_sw.cpu().numpy(), L, cw=cw)
+    got = d_cnt.cpu().numpy().astype(np.uint64)
+    assert (got == want).all() and 0 < got[1] < F and got[10] > 0
+    dec.set_generator(None)
+
+
+def test_simulate_with_generator(sys_code, oracle):
+    """The whole leg with random codewords: equal to the all-zero leg on the BSC (the decoder is symmetric
+    and r = c ^ flips mirrors the LLRs exactly) and to the checker's leg with the same G."""
+    c = sys_code
+    dec, g = c["dec"], c["g"]
+    for ch, e in ((oracle.CH_BSC_INFO, 0.035), (oracle.CH_BSC_ALL, 0.022)):
+        dec.set_generator(None)
+        zero = dec.simulate(ch, e, seed=3, first_frame=10, frames=3000, max_iters=40)
+        dec.set_generator(c["eg"])
+        rand = dec.simulate(ch, e, seed=3, first_frame=10, frames=3000, max_iters=40)
+        assert 0 < zero[1] < 3000 and (zero == rand).all(), (zero[:12], rand[:12])
+        want = g.simulate(ch, e, seed=3, first_frame=10, frames=3000, max_iters=40, G=c["eg"])
+        assert rand[10] == want[10] and rand[11] == want[11]
+        assert abs(int(rand[1]) - int(want[1])) <= 2 and abs(int(rand[8]) - int(want[8])) <= 90, (rand[:12], want[:12])
+    rand = dec.simulate(oracle.CH_AWGN, 3.5, seed=3, first_frame=0, frames=3000, max_iters=40)
+    want = g.simulate(oracle.CH_AWGN, 3.5, seed=3, first_frame=0, frames=3000, max_iters=40, G=c["eg"])
+    assert abs(int(rand[10]) - int(want[10])) <= 2 and abs(int(rand[1]) - int(want[1])) <= 2, (rand[:12], want[:12])
+    dec.set_generator(None)
