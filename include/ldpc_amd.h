@@ -55,7 +55,8 @@ extern "C" {
 #define LDPC_AMD_LLR_PARITY_1EM7 2   /* j >= n-m get +-ln((1-1e-7)/1e-7), MinSumDecoder.java:41 */
 
 /* channels of ldpc_amd_simulate */
-#define LDPC_AMD_CH_BSC_INFO 0 /* flips on j < n-m only, Channel.java:5-17; LLRs as LogDecoder */
+#define LDPC_AMD_CH_BSC_INFO 0 /* flips on j < n-m only, Channel.java:5-17; LLRs as LogDecoder, or as
+                                  MinSumDecoder (parity +-ln((1-1e-7)/1e-7)) under LDPC_AMD_CN_MINSUM */
 #define LDPC_AMD_CH_BSC_ALL 1  /* flips everywhere, Channel.java:28-39; LLRs as LogDecoderBefore */
 #define LDPC_AMD_CH_AWGN 2     /* BPSK + AWGN at Eb/N0 dB (not in the reference) */
 

@@ -798,7 +798,9 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
     double l0 = 0.0, l1 = 0.0;
     const bool awgn = channel == LDPC_AMD_CH_AWGN;
     if (!awgn) {
-        const int mode = (channel == LDPC_AMD_CH_BSC_INFO) ? LDPC_AMD_LLR_PARITY_LN1E20 : LDPC_AMD_LLR_UNIFORM;
+        // the parity LLR constant belongs to the decoder class: LogDecoder.java:47 vs MinSumDecoder.java:41
+        const int parity_mode = (c->cn_rule == LDPC_AMD_CN_MINSUM) ? LDPC_AMD_LLR_PARITY_1EM7 : LDPC_AMD_LLR_PARITY_LN1E20;
+        const int mode = (channel == LDPC_AMD_CH_BSC_INFO) ? parity_mode : LDPC_AMD_LLR_UNIFORM;
         if (int rc = bsc_magnitudes(c, param, mode, &l0, &l1)) return rc;
     }
     const size_t in_elem = awgn ? sizeof(float) : 1;

@@ -535,7 +535,9 @@ int oracle_simulate(const oracle_graph* g, int gen_k, const uint8_t* G, int chan
             for (int64_t t = 0; t < nf * n; t++) r[t] = (llr[t] < 0.0f) ? 1 : 0;
         } else {
             oracle_gen_bsc(m, n, channel, param, seed, first_frame + f0, nf, cw, r);
-            const int mode = (channel == ORACLE_CH_BSC_INFO) ? ORACLE_LLR_PARITY_LN1E20 : ORACLE_LLR_UNIFORM;
+            /* LogDecoder.java:47 / MinSumDecoder.java:41: the parity constant goes with the decoder class */
+            const int pmode = (cn_rule == ORACLE_CN_MINSUM) ? ORACLE_LLR_PARITY_1EM7 : ORACLE_LLR_PARITY_LN1E20;
+            const int mode = (channel == ORACLE_CH_BSC_INFO) ? pmode : ORACLE_LLR_UNIFORM;
             for (int64_t f = 0; f < nf; f++) {
                 oracle_bsc_llr(m, n, r + f * n, param, mode, tmp);
                 /* the device path stores channel LLRs as float */
