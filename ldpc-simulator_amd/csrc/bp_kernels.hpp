@@ -26,7 +26,7 @@ namespace ldpc {
 constexpr int kWave = 64;
 constexpr int kCnSumProduct = 0;
 constexpr int kCnMinSum = 1;
-constexpr int kCnLogTanh = 2;
+constexpr int kCnTanhPair = 2;
 // node degrees handled in registers with 1 frame per lane (larger rows are staged through LDS);
 // a translation unit may raise them for its own kernels
 #ifndef LDPC_REG_DEG_CN
@@ -136,17 +136,22 @@ __device__ __forceinline__ float atanh2(float p) {
 // Math.signum: +-0 and NaN map to themselves (MinSumDecoder.java:84)
 __device__ __forceinline__ float signum(float x) { return (x > 0.0f) ? 1.0f : (x < 0.0f) ? -1.0f : x; }
 
-// ---- the sum-product rule in the (sign, phi) domain ------------------------------------------
-// phi(x) = -ln tanh(x/2) = ln((1 + w)/(1 - w)), w = e^-x, for x >= 0; phi is its own inverse.
-// 2 atanh(prod tanh(beta_k/2)) equals  sign * phi(sum phi(|beta_k|)), and in this form fp32 stays
-// accurate over the whole range in which the double-precision reference is finite: 1 - tanh never
-// has to be formed from a value rounded next to 1.  phi(0) = +Inf (2/0), phi(+Inf) = 0, phi(NaN) = NaN.
+// ---- the sum-product rule on (tanh, 1 - tanh) pairs ---------------------------------------------
+// 2 atanh(prod tanh(|beta_k|/2)) with every factor t_k carried together with its complement
+// q_k = 1 - t_k = 2w/(1 + w), w = e^-|beta_k|, which is formed directly (no cancellation), and every
+// partial product P carried together with ITS complement Q = 1 - P through
+//     (P, Q) * (t, q) = (P t, q + t Q)          and          (P1, Q1) * (P2, Q2) = (P1 P2, Q1 + P1 Q2),
+// sums of non-negative terms only.  Then alpha = ln((1 + P)/(1 - P)) = ln(Q + 2P) - ln Q keeps full
+// relative accuracy in fp32 over the whole range in which the double-precision reference is finite:
+// 1 - P is never formed from a value rounded next to 1.  Q = 0 (every other member saturated) gives
+// +Inf, P = 0 (a member with beta = 0) gives exactly 0 because the two logarithms then have the same
+// argument, NaN stays NaN.  Per edge this costs exp2, rcp and two log2.
 //
 // Everything below is written once for V = float and V = v2f (two independent checks per lane): on
 // gfx950 a plain fp32 VALU instruction and a packed one (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
-// cost the same issue cycles, so the packed form halves the cost of the polynomial and
-// bookkeeping arithmetic.  Both instantiate the same operations in the same order (fused
-// multiply-adds only where written), so they return identical bits per element.
+// cost the same issue cycles, so the packed form halves the cost of the bookkeeping arithmetic.
+// Both instantiate the same operations in the same order (fused multiply-adds only where written),
+// so they return identical bits per element.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float vexp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -172,81 +177,65 @@ __device__ __forceinline__ float vsign1(float x) {
     return __uint_as_float((__float_as_uint(x) & 0x80000000u) | 0x3f800000u);
 }
 __device__ __forceinline__ v2f vsign1(v2f x) { return v2f{vsign1(x.x), vsign1(x.y)}; }
+__device__ __forceinline__ float vabs(float x) { return fabsf(x); }
+__device__ __forceinline__ v2f vabs(v2f x) { return v2f{fabsf(x.x), fabsf(x.y)}; }
 template <class V> __device__ __forceinline__ V vsplat(float x);
 template <> __device__ __forceinline__ float vsplat<float>(float x) { return x; }
 template <> __device__ __forceinline__ v2f vsplat<v2f>(float x) { return v2f{x, x}; }
 
 // Units: with this rule every LLR and message is held in BITS (natural-log value / ln 2; the layout
-// kernels scale the channel LLRs once on the way in, decisions only need signs).  Then
-// w = 2^-x is the bare hardware exp2 and phi comes straight out of the hardware log2: the four
-// multiplications by ln 2 / log2 e per edge disappear, and the constants of the two series absorb
-// the factor.  Below, x, S and phi are all in bits.
+// kernels scale the channel LLRs once on the way in, decisions only need signs).  Then w = 2^-x is
+// the bare hardware exp2 and alpha comes straight out of the hardware log2, with no constants.
 //
-// Input side, x = |beta|.  For a confident message (w small) log2(1 + 2w + ...) would cancel, and the
-// sum S of such terms decides a large alpha, so there 2 atanh(w) / ln 2 comes from its series.  For a
-// weak message (x -> 0) 1 - w carries an absolute error of one ulp of 1; phi is then large and its
-// error only rescales an alpha that is already ~2^-phi, far below fp32 resolution of the posterior sums.
-template <class V>
-__device__ __forceinline__ V phi_in(V x) {
-#pragma clang fp contract(off)
-    const V one = vsplat<V>(1.0f);
-    const V w = vexp2(-x);
-    const V big = vlog2((one + w) * vrcp(one - w));
-    const V w2 = w * w;
-    // (2 / ln 2) (w + w^3/3 + w^5/5); w < 0.1: next term w^6/7 < 1.5e-7 relative
-    const V ser = w * vfma(w2, vfma(w2, vsplat<V>(0.5770780163555854f), vsplat<V>(0.9617966939259756f)),
-                           vsplat<V>(2.8853900817779268f));
-    return vsel_lt(w, 0.1f, ser, big);
-}
-
-// Output side, x = S = sum of input-side terms.  Small S means every other member is confident and
-// alpha = log2(2/(S ln 2) - ...) is large: 1 - 2^-S must keep full relative accuracy, so below
-// S ln 2 = 1/8 it comes from the Taylor polynomial of 1 - e^-y, y = S ln 2.  Large S gives a small
-// alpha whose absolute error (one ulp of 1 inside the logarithm) is below the resolution of the sums
-// it enters.
-template <class V>
-__device__ __forceinline__ V phi_out(V x) {
-#pragma clang fp contract(off)
-    const V one = vsplat<V>(1.0f);
-    const V w = vexp2(-x);
-    // x (L - L^2 x/2 + L^3 x^2/6 - L^4 x^3/24 + L^5 x^4/120), L = ln 2; next term < 5e-8 relative at y = 1/8
-    const V poly = x * vfma(x, vfma(x, vfma(x, vfma(x, vsplat<V>(1.3333558146428443e-3f), vsplat<V>(-9.618129107628477e-3f)),
-                                            vsplat<V>(5.550410866482158e-2f)), vsplat<V>(-0.2402265069591007f)),
-                            vsplat<V>(0.6931471805599453f));
-    const V omw = vsel_lt(x, 0.18033688011112042f, poly, one - w);
-    return vlog2((one + w) * vrcp(omw));
-}
-
 // |beta| above 55 ln 2 nats = 55 bits has tanh(beta/2) == 1.0 in double (1 - tanh < 2^-54): the
-// reference's factor is exactly 1 there, so its log-domain term is exactly 0.
+// reference's factor is exactly 1 there, so q is exactly 0 (a select on the argument: no branch).
 constexpr float kDoubleTanhSaturation = 55.0f;   // bits
 constexpr float kBitsPerNat = 1.4426950408889634f;  // 1 / ln 2: scale of the channel LLRs for this rule
 
-// beta[0..D) -> alpha[0..D) in place.  Sums ascend over k like the products of LogDecoder.java:86-91
-// they stand for; leave-one-out is (prefix of k) + (suffix of k), signs likewise by products of +-1.
-template <class V, int D>
-__device__ __forceinline__ void cn_logtanh(V (&b)[D]) {
+// q = 1 - tanh(|beta| ln2 / 2), beta in bits; beta = 0 gives exactly 1, |beta| > 55 exactly 0.
+// |beta| is only ever a source modifier of the exp2 and of the comparison.
+template <class V>
+__device__ __forceinline__ V tanh_complement(V beta) {
 #pragma clang fp contract(off)
-    V ph[D], sg[D], pre[D], psg[D];
-    V run = vsplat<V>(0.0f), rs = vsplat<V>(1.0f);
+    const V x = vabs(beta);
+    const V w = vsel_gt(x, kDoubleTanhSaturation, vsplat<V>(0.0f), vexp2(-x));
+    return w * vrcp(vfma(w, vsplat<V>(0.5f), vsplat<V>(0.5f)));
+}
+
+// |alpha| in bits from a leave-one-out product P and its complement Q
+template <class V>
+__device__ __forceinline__ V atanh2_pair(V P, V Q) {
+#pragma clang fp contract(off)
+    return vlog2(vfma(P, vsplat<V>(2.0f), Q)) - vlog2(Q);
+}
+
+// beta[0..D) -> alpha[0..D) in place.  Products ascend over k like those of LogDecoder.java:86-91;
+// leave-one-out is (prefix of k) * (suffix of k).  The sign of alpha_k is the product of the other
+// members' signs, formed as (product of all) * (own): exact for factors of +-1.
+template <class V, int D>
+__device__ __forceinline__ void cn_tanh_pair(V (&b)[D]) {
+#pragma clang fp contract(off)
+    const V one = vsplat<V>(1.0f);
+    V q[D], t[D], sg[D], pp[D], pq[D];
+    V P = one, Q = vsplat<V>(0.0f), all = one;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         sg[k] = vsign1(b[k]);
-        const V a = b[k] * sg[k];
-        // saturated input -> e^-inf = 0 -> phi = 0 exactly (a select on the argument: no branch)
-        ph[k] = phi_in<V>(vsel_gt(a, kDoubleTanhSaturation, vsplat<V>(__builtin_inff()), a));
-        pre[k] = run;
-        psg[k] = rs;
-        run = run + ph[k];
-        rs = rs * sg[k];
+        q[k] = tanh_complement<V>(b[k]);
+        t[k] = one - q[k];
+        pp[k] = P;
+        pq[k] = Q;
+        P = P * t[k];
+        Q = vfma(Q, t[k], q[k]);
+        all = all * sg[k];
     }
-    V suf = vsplat<V>(0.0f), ss = vsplat<V>(1.0f);
+    V sP = one, sQ = vsplat<V>(0.0f);
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
-        const V mag = phi_out<V>(pre[k] + suf);
-        b[k] = mag * (psg[k] * ss);
-        suf = suf + ph[k];
-        ss = ss * sg[k];
+        const V mag = atanh2_pair<V>(pp[k] * sP, vfma(sQ, pp[k], pq[k]));
+        b[k] = mag * (all * sg[k]);
+        sP = sP * t[k];
+        sQ = vfma(sQ, t[k], q[k]);
     }
 }
 
@@ -270,8 +259,8 @@ __device__ __forceinline__ void cn_compute1(float (&b)[D]) {
             suf *= b[k];
             b[k] = atanh2(p);
         }
-    } else if constexpr (RULE == kCnLogTanh) {
-        cn_logtanh<float, D>(b);
+    } else if constexpr (RULE == kCnTanhPair) {
+        cn_tanh_pair<float, D>(b);
     } else {
         // MinSumDecoder.java:79-93: alpha = prod signum(beta) * min|beta| * 0.7 over k != j;
         // "minbata > |beta|" never selects a NaN, and Double.MAX_VALUE becomes FLT_MAX.
@@ -353,28 +342,36 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
             suf *= st[k * 64];
             row[(long long)k * T] = atanh2(p);
         }
-    } else if constexpr (RULE == kCnLogTanh) {
-        // staged: phi_k with sign(beta_k) in its sign bit; exclusive prefix sum with the prefix sign
-        float pre = 0.0f;
+    } else if constexpr (RULE == kCnTanhPair) {
+#pragma clang fp contract(off)
+        // staged: the exclusive prefix pair (P with the prefix sign in its sign bit, Q); the factors
+        // are formed again from beta on the way back (two more transcendentals per edge on this rare
+        // path, in exchange for two LDS arrays instead of three)
+        float P = 1.0f, Q = 0.0f;
         uint32_t psg = 0u;
         for (int k = 0; k < d; ++k) {
-            float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
-            const float a = fabsf(b);
-            const uint32_t sg = __float_as_uint(b) & 0x80000000u;
-            const float ph = phi_in<float>((a > kDoubleTanhSaturation) ? __builtin_inff() : a);
-            st[k * 64] = __uint_as_float(__float_as_uint(ph) | sg);
-            sp[k * 64] = __uint_as_float(__float_as_uint(pre) | psg);
-            pre += ph;
-            psg ^= sg;
+            const float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
+            const float qk = tanh_complement<float>(b);
+            const float tk = 1.0f - qk;
+            st[k * 64] = __uint_as_float(__float_as_uint(P) | psg);
+            sp[k * 64] = Q;
+            P = P * tk;
+            Q = fmaf(Q, tk, qk);
+            psg ^= __float_as_uint(b) & 0x80000000u;
         }
-        float suf = 0.0f;
+        float sP = 1.0f, sQ = 0.0f;
         uint32_t ssg = 0u;
         for (int k = d - 1; k >= 0; --k) {
-            const float sv = st[k * 64], pv = sp[k * 64];
-            const float mag = phi_out<float>(fabsf(pv) + suf);
+            const float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
+            const float qk = tanh_complement<float>(b);
+            const float tk = 1.0f - qk;
+            const float pv = st[k * 64];
+            const float pk = fabsf(pv);
+            const float mag = atanh2_pair<float>(pk * sP, fmaf(sQ, pk, sp[k * 64]));
             row[(long long)k * T] = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(pv) & 0x80000000u) ^ ssg);
-            suf += fabsf(sv);
-            ssg ^= __float_as_uint(sv) & 0x80000000u;
+            sP = sP * tk;
+            sQ = fmaf(sQ, tk, qk);
+            ssg ^= __float_as_uint(b) & 0x80000000u;
         }
     } else {
         // beta and the exclusive prefix minimum are staged; the exclusive prefix sign product
@@ -430,6 +427,24 @@ __device__ __forceinline__ void vn_compute(float (&a)[D][FPL], const float (&lam
                 suf[f] = ak + suf[f];
             }
         }
+}
+
+// the same sums on one value type (float, or v2f = two variables per lane in packed registers)
+template <class V, int D>
+__device__ __forceinline__ void vn_compute_v(V (&a)[D], V lam, V& g) {
+    V pre[D + 1];
+    pre[0] = lam;
+#pragma unroll
+    for (int k = 0; k < D; ++k) pre[k + 1] = pre[k] + a[k];
+    g = pre[D];
+    V suf = a[D - 1];
+    a[D - 1] = pre[D - 1];
+#pragma unroll
+    for (int k = D - 2; k >= 0; --k) {
+        const V ak = a[k];
+        a[k] = pre[k] + suf;
+        suf = ak + suf;
+    }
 }
 
 template <int FPL, int D>
@@ -765,7 +780,7 @@ __global__ void __launch_bounds__(256, WPS) bp_decode_kernel(BpParams p) {
 // One launcher per (DC, DV) specialisation, each compiled in its own translation unit.
 struct BpLaunch {
     int fpl;     // frames per lane: 1, 2 or 4
-    int rule;    // kCnLogTanh / kCnSumProduct / kCnMinSum
+    int rule;    // kCnTanhPair / kCnSumProduct / kCnMinSum
     bool early;  // per-frame early termination (fpl == 1 only)
     int wps;     // 2 or 4 waves per SIMD (2 only with fpl == 4)
     dim3 grid, block;
@@ -783,7 +798,7 @@ inline void bp_launch_impl(const BpLaunch& l, const BpParams& p) {
     switch (l.rule) {                                            \
         case kCnMinSum: LDPC_LAUNCH(F, kCnMinSum, E); break;     \
         case kCnSumProduct: LDPC_LAUNCH(F, kCnSumProduct, E); break; \
-        default: LDPC_LAUNCH(F, kCnLogTanh, E); break;           \
+        default: LDPC_LAUNCH(F, kCnTanhPair, E); break;           \
     }
     if (l.fpl == 1) {
         if (l.early) { LDPC_BY_RULE(1, true) } else { LDPC_BY_RULE(1, false) }

@@ -52,6 +52,14 @@ __host__ __device__ inline int lds_slot(int e, int dc, int nt) {
     return 2 * dc * (t + (c >> 1) * nt) + 2 * k + (c & 1);
 }
 
+// LDS accesses by 32-bit LDS address
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ uint32_t lds_address(const void* generic) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)generic;
+}
+__device__ __forceinline__ float lds_load(uint32_t a) { return *(const lds_float*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_store(uint32_t a, float v) { *(lds_float*)(uintptr_t)a = v; }
+
 // number of unsatisfied checks of the decisions in `bits` (sumSyndro, LogDecoder.java:108-116);
 // bits are indexed by VN position, edge_pos maps an edge to the position of its variable
 template <int DC>
@@ -79,7 +87,7 @@ __device__ __forceinline__ int lds_syndrome(const LdsParams& p, const uint32_t* 
 // CPT (even) checks and kLdsVpt variables per thread, exactly: m = CPT * blockDim.x, n = kLdsVpt * blockDim.x.
 template <int DC, int DV, int RULE, bool EARLY, int CPT>
 __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
-    static_assert(CPT % 2 == 0, "checks are processed in pairs");
+    static_assert(CPT % 2 == 0 && kLdsVpt % 2 == 0, "checks and variables are processed in pairs");
     extern __shared__ __align__(16) float smem[];
     float* msg = smem;                                   // [E]
     float* lam = smem + p.E;                             // [n], by VN position
@@ -90,12 +98,16 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
     if (frame >= p.frames) return;
     char* msgb = reinterpret_cast<char*>(msg);
 
-    // byte offsets of the edge slots of this thread's variables: fixed for the whole decode
-    int off[kLdsVpt][DV];
+    // LDS addresses of the edge slots of this thread's variables: fixed for the whole decode, and
+    // kept opaque so that they stay in registers instead of being re-formed as base + offset per use
+    uint32_t off[kLdsVpt][DV];
 #pragma unroll
     for (int v = 0; v < kLdsVpt; ++v)
 #pragma unroll
-        for (int k = 0; k < DV; ++k) off[v][k] = p.vn_off[(long long)(t + v * nt) * DV + k];
+        for (int k = 0; k < DV; ++k) {
+            off[v][k] = lds_address(msgb + p.vn_off[(long long)(t + v * nt) * DV + k]);
+            asm volatile("" : "+v"(off[v][k]));
+        }
     // channel LLRs of the frame -> LDS, in VN position order
     if (p.llr) {
         const float* src = p.llr + frame * p.n;
@@ -128,8 +140,8 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
 #pragma unroll
         for (int q = 0; q < CPT / 2; ++q) {
             v2f* row = reinterpret_cast<v2f*>(msg + 2 * DC * (t + q * nt));
-            if constexpr (RULE == kCnLogTanh) {
-                cn_logtanh<v2f, DC>(x[q]);
+            if constexpr (RULE == kCnTanhPair) {
+                cn_tanh_pair<v2f, DC>(x[q]);
             } else {
                 float xa[DC], xb[DC];
 #pragma unroll
@@ -146,27 +158,33 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit
         // (all gathers are issued before any scatter: distinct variables never share a slot)
         const bool write_beta = EARLY || (it + 1 < p.max_iters);
-        float va[kLdsVpt][DV][1], vl[kLdsVpt][1];
+        v2f va[kLdsVpt / 2][DV], vl[kLdsVpt / 2];
 #pragma unroll
-        for (int v = 0; v < kLdsVpt; ++v) {
+        for (int v = 0; v < kLdsVpt; v += 2) {
 #pragma unroll
-            for (int k = 0; k < DV; ++k) va[v][k][0] = *reinterpret_cast<const float*>(msgb + off[v][k]);
-            vl[v][0] = lam[t + v * nt];
+            for (int k = 0; k < DV; ++k) va[v / 2][k] = v2f{lds_load(off[v][k]), lds_load(off[v + 1][k])};
+            vl[v / 2] = v2f{lam[t + v * nt], lam[t + (v + 1) * nt]};
         }
 #pragma unroll
-        for (int v = 0; v < kLdsVpt; ++v) {
-            const int q = t + v * nt;
-            float g[1];
-            vn_compute<1, DV>(va[v], vl[v], g);
+        for (int v = 0; v < kLdsVpt; v += 2) {
+            v2f g;
+            vn_compute_v<v2f, DV>(va[v / 2], vl[v / 2], g);   // two variables per packed register
             if (write_beta) {
 #pragma unroll
-                for (int k = 0; k < DV; ++k) *reinterpret_cast<float*>(msgb + off[v][k]) = va[v][k][0];
+                for (int k = 0; k < DV; ++k) {
+                    lds_store(off[v][k], va[v / 2][k].x);
+                    lds_store(off[v + 1][k], va[v / 2][k].y);
+                }
             }
             if (EARLY || it + 1 == p.max_iters) {
-                const unsigned long long mask = __ballot(g[0] < 0.0f);  // "(gamma[j] < 0) ? 1 : 0", :104
-                if ((t & 63) == 0) {  // q is a multiple of 64 here and n a multiple of 64
-                    bits[q >> 5] = (uint32_t)mask;
-                    bits[(q >> 5) + 1] = (uint32_t)(mask >> 32);
+                // "(gamma[j] < 0) ? 1 : 0", :104; q is a multiple of 64 in lane 0 and n a multiple of 64
+                const unsigned long long m0 = __ballot(g.x < 0.0f), m1 = __ballot(g.y < 0.0f);
+                if ((t & 63) == 0) {
+                    const int q0 = t + v * nt, q1 = t + (v + 1) * nt;
+                    bits[q0 >> 5] = (uint32_t)m0;
+                    bits[(q0 >> 5) + 1] = (uint32_t)(m0 >> 32);
+                    bits[q1 >> 5] = (uint32_t)m1;
+                    bits[(q1 >> 5) + 1] = (uint32_t)(m1 >> 32);
                 }
             }
         }
@@ -223,7 +241,7 @@ inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
     switch (l.rule) {
         case kCnMinSum: if (l.early) LDPC_LDS(kCnMinSum, true); else LDPC_LDS(kCnMinSum, false); break;
         case kCnSumProduct: if (l.early) LDPC_LDS(kCnSumProduct, true); else LDPC_LDS(kCnSumProduct, false); break;
-        default: if (l.early) LDPC_LDS(kCnLogTanh, true); else LDPC_LDS(kCnLogTanh, false); break;
+        default: if (l.early) LDPC_LDS(kCnTanhPair, true); else LDPC_LDS(kCnTanhPair, false); break;
     }
 #undef LDPC_LDS
     return hipGetLastError();

@@ -252,7 +252,7 @@ int launch_bp(ldpc_amd_ctx* c, const BpParams& p, int fpl, bool early, int wpb, 
     BpLaunch l;
     l.fpl = fpl;
     l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
-             : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnLogTanh;
+             : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnTanhPair;
     l.early = early;
     l.wps = fpl == 4 ? 2 : 4;  // 4 frames per lane need ~180 VGPRs to stay out of scratch
     if (const char* env = getenv("LDPC_AMD_WPS")) l.wps = atoi(env) == 2 ? 2 : 4;
@@ -306,7 +306,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             q.hard = d_hard; q.out_iters = d_iters; q.out_synd = d_synd;
             LdsLaunch l;
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
-                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnLogTanh;
+                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnTanhPair;
             l.early = early; l.threads = nt; l.lds_bytes = lds_bytes; l.stream = s;
             while (c->ev.size() < 2) {
                 hipEvent_t e;
@@ -442,7 +442,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             RowsLaunch l;
             l.fpl = fpl == 4 ? 4 : 1;
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
-                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnLogTanh;
+                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnTanhPair;
             l.chunks = chunks; l.wpb = wpb; l.lds_bytes = lds_bytes; l.stream = s;
             LDPC_HIP(c, bp_rows_run(l, q));
         } else if (int rc = launch_bp(c, p, fpl, early, wpb, lds_bytes, pipelined, s)) {
