@@ -26,7 +26,7 @@ namespace ldpc {
 constexpr int kWave = 64;
 constexpr int kCnSumProduct = 0;
 constexpr int kCnMinSum = 1;
-constexpr int kCnTanhPair = 2;
+constexpr int kCnComplement = 2;
 // node degrees handled in registers with 1 frame per lane (larger rows are staged through LDS);
 // a translation unit may raise them for its own kernels
 #ifndef LDPC_REG_DEG_CN
@@ -136,16 +136,17 @@ __device__ __forceinline__ float atanh2(float p) {
 // Math.signum: +-0 and NaN map to themselves (MinSumDecoder.java:84)
 __device__ __forceinline__ float signum(float x) { return (x > 0.0f) ? 1.0f : (x < 0.0f) ? -1.0f : x; }
 
-// ---- the sum-product rule on (tanh, 1 - tanh) pairs ---------------------------------------------
-// 2 atanh(prod tanh(|beta_k|/2)) with every factor t_k carried together with its complement
+// ---- the sum-product rule on complements ------------------------------------------------------
+// 2 atanh(prod tanh(|beta_k|/2)) with every factor t_k represented by its complement
 // q_k = 1 - t_k = 2w/(1 + w), w = e^-|beta_k|, which is formed directly (no cancellation), and every
-// partial product P carried together with ITS complement Q = 1 - P through
-//     (P, Q) * (t, q) = (P t, q + t Q)          and          (P1, Q1) * (P2, Q2) = (P1 P2, Q1 + P1 Q2),
-// sums of non-negative terms only.  Then alpha = ln((1 + P)/(1 - P)) = ln(Q + 2P) - ln Q keeps full
-// relative accuracy in fp32 over the whole range in which the double-precision reference is finite:
-// 1 - P is never formed from a value rounded next to 1.  Q = 0 (every other member saturated) gives
-// +Inf, P = 0 (a member with beta = 0) gives exactly 0 because the two logarithms then have the same
-// argument, NaN stays NaN.  Per edge this costs exp2, rcp and two log2.
+// partial product P represented by ITS complement Q = 1 - P through
+//     Q(P t) = q + t Q          and          Q(P1 P2) = Q1 + (1 - Q1) Q2,
+// sums of non-negative terms only.  Then alpha = ln((1 + P)/(1 - P)) = ln(2 - Q) - ln Q keeps full
+// relative accuracy in fp32 where alpha is large (Q small: 1 - P is never formed from a value rounded
+// next to 1) and an absolute error of an ulp of 1 where alpha is small, over the whole range in which
+// the double-precision reference is finite.  Q = 0 (every other member saturated) gives +Inf; a
+// member with beta = 0 has q = 1, which makes Q exactly 1 and alpha exactly 0; NaN stays NaN.
+// Per edge this costs exp2, rcp and two log2.
 //
 // Everything below is written once for V = float and V = v2f (two independent checks per lane): on
 // gfx950 a plain fp32 VALU instruction and a packed one (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
@@ -202,39 +203,36 @@ __device__ __forceinline__ V tanh_complement(V beta) {
     return w * vrcp(vfma(w, vsplat<V>(0.5f), vsplat<V>(0.5f)));
 }
 
-// |alpha| in bits from a leave-one-out product P and its complement Q
+// |alpha| in bits from the complement Q of a leave-one-out product
 template <class V>
-__device__ __forceinline__ V atanh2_pair(V P, V Q) {
+__device__ __forceinline__ V atanh2_complement(V Q) {
 #pragma clang fp contract(off)
-    return vlog2(vfma(P, vsplat<V>(2.0f), Q)) - vlog2(Q);
+    return vlog2(vsplat<V>(2.0f) - Q) - vlog2(Q);
 }
 
 // beta[0..D) -> alpha[0..D) in place.  Products ascend over k like those of LogDecoder.java:86-91;
 // leave-one-out is (prefix of k) * (suffix of k).  The sign of alpha_k is the product of the other
 // members' signs, formed as (product of all) * (own): exact for factors of +-1.
 template <class V, int D>
-__device__ __forceinline__ void cn_tanh_pair(V (&b)[D]) {
+__device__ __forceinline__ void cn_complement(V (&b)[D]) {
 #pragma clang fp contract(off)
     const V one = vsplat<V>(1.0f);
-    V q[D], t[D], sg[D], pp[D], pq[D];
-    V P = one, Q = vsplat<V>(0.0f), all = one;
+    V q[D], t[D], sg[D], pq[D];
+    V Q = vsplat<V>(0.0f), all = one;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         sg[k] = vsign1(b[k]);
         q[k] = tanh_complement<V>(b[k]);
         t[k] = one - q[k];
-        pp[k] = P;
         pq[k] = Q;
-        P = P * t[k];
         Q = vfma(Q, t[k], q[k]);
         all = all * sg[k];
     }
-    V sP = one, sQ = vsplat<V>(0.0f);
+    V sQ = vsplat<V>(0.0f);
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
-        const V mag = atanh2_pair<V>(pp[k] * sP, vfma(sQ, pp[k], pq[k]));
+        const V mag = atanh2_complement<V>(vfma(sQ, one - pq[k], pq[k]));
         b[k] = mag * (all * sg[k]);
-        sP = sP * t[k];
         sQ = vfma(sQ, t[k], q[k]);
     }
 }
@@ -259,8 +257,8 @@ __device__ __forceinline__ void cn_compute1(float (&b)[D]) {
             suf *= b[k];
             b[k] = atanh2(p);
         }
-    } else if constexpr (RULE == kCnTanhPair) {
-        cn_tanh_pair<float, D>(b);
+    } else if constexpr (RULE == kCnComplement) {
+        cn_complement<float, D>(b);
     } else {
         // MinSumDecoder.java:79-93: alpha = prod signum(beta) * min|beta| * 0.7 over k != j;
         // "minbata > |beta|" never selects a NaN, and Double.MAX_VALUE becomes FLT_MAX.
@@ -342,36 +340,29 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
             suf *= st[k * 64];
             row[(long long)k * T] = atanh2(p);
         }
-    } else if constexpr (RULE == kCnTanhPair) {
+    } else if constexpr (RULE == kCnComplement) {
 #pragma clang fp contract(off)
-        // staged: the exclusive prefix pair (P with the prefix sign in its sign bit, Q); the factors
-        // are formed again from beta on the way back (two more transcendentals per edge on this rare
-        // path, in exchange for two LDS arrays instead of three)
-        float P = 1.0f, Q = 0.0f;
+        // staged: q_k with sign(beta_k) in its sign bit; the exclusive prefix complement with the prefix sign
+        float Q = 0.0f;
         uint32_t psg = 0u;
         for (int k = 0; k < d; ++k) {
             const float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
+            const uint32_t sg = __float_as_uint(b) & 0x80000000u;
             const float qk = tanh_complement<float>(b);
-            const float tk = 1.0f - qk;
-            st[k * 64] = __uint_as_float(__float_as_uint(P) | psg);
-            sp[k * 64] = Q;
-            P = P * tk;
-            Q = fmaf(Q, tk, qk);
-            psg ^= __float_as_uint(b) & 0x80000000u;
+            st[k * 64] = __uint_as_float(__float_as_uint(qk) | sg);
+            sp[k * 64] = __uint_as_float(__float_as_uint(Q) | psg);
+            Q = fmaf(Q, 1.0f - qk, qk);
+            psg ^= sg;
         }
-        float sP = 1.0f, sQ = 0.0f;
+        float sQ = 0.0f;
         uint32_t ssg = 0u;
         for (int k = d - 1; k >= 0; --k) {
-            const float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
-            const float qk = tanh_complement<float>(b);
-            const float tk = 1.0f - qk;
-            const float pv = st[k * 64];
-            const float pk = fabsf(pv);
-            const float mag = atanh2_pair<float>(pk * sP, fmaf(sQ, pk, sp[k * 64]));
+            const float sv = st[k * 64], pv = sp[k * 64];
+            const float qk = fabsf(sv), pq = fabsf(pv);
+            const float mag = atanh2_complement<float>(fmaf(sQ, 1.0f - pq, pq));
             row[(long long)k * T] = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(pv) & 0x80000000u) ^ ssg);
-            sP = sP * tk;
-            sQ = fmaf(sQ, tk, qk);
-            ssg ^= __float_as_uint(b) & 0x80000000u;
+            sQ = fmaf(sQ, 1.0f - qk, qk);
+            ssg ^= __float_as_uint(sv) & 0x80000000u;
         }
     } else {
         // beta and the exclusive prefix minimum are staged; the exclusive prefix sign product
@@ -780,7 +771,7 @@ __global__ void __launch_bounds__(256, WPS) bp_decode_kernel(BpParams p) {
 // One launcher per (DC, DV) specialisation, each compiled in its own translation unit.
 struct BpLaunch {
     int fpl;     // frames per lane: 1, 2 or 4
-    int rule;    // kCnTanhPair / kCnSumProduct / kCnMinSum
+    int rule;    // kCnComplement / kCnSumProduct / kCnMinSum
     bool early;  // per-frame early termination (fpl == 1 only)
     int wps;     // 2 or 4 waves per SIMD (2 only with fpl == 4)
     dim3 grid, block;
@@ -798,7 +789,7 @@ inline void bp_launch_impl(const BpLaunch& l, const BpParams& p) {
     switch (l.rule) {                                            \
         case kCnMinSum: LDPC_LAUNCH(F, kCnMinSum, E); break;     \
         case kCnSumProduct: LDPC_LAUNCH(F, kCnSumProduct, E); break; \
-        default: LDPC_LAUNCH(F, kCnTanhPair, E); break;           \
+        default: LDPC_LAUNCH(F, kCnComplement, E); break;           \
     }
     if (l.fpl == 1) {
         if (l.early) { LDPC_BY_RULE(1, true) } else { LDPC_BY_RULE(1, false) }

@@ -1,7 +1,8 @@
 // Frame-resident flooding belief propagation for gfx950: one workgroup decodes one frame whose whole
 // message state lives in LDS, so HBM sees only the channel LLRs in and the hard decisions out.
 //
-// Used for regular codes whose state fits on chip (E + n floats <= ~78 KiB, two workgroups per CU).
+// Used for regular codes whose messages fit on chip (E floats <= ~78 KiB, two workgroups per CU;
+// the channel LLRs of a thread's own variables stay in its registers).
 // The arithmetic is the same code as the streaming kernels (cn_compute1 / vn_compute in
 // bp_kernels.hpp): same neighbour order, same prefix x suffix leave-one-out, so both engines return
 // identical bits.  What changes is the mapping:
@@ -31,6 +32,7 @@ struct LdsParams {
     const int* vn_off;     // [n*DV] byte offset in msg of edge k of the variable at position p, [p*DV + k]
     const int* edge_slot;  // [E]  LDS slot of CSR edge e
     const int* edge_pos;   // [E]  VN position of the variable of CSR edge e (its decision bit index)
+    const int* edge_col;   // [E]  variable of CSR edge e
     const float* llr;      // [frames][n] channel LLRs, or null
     const uint8_t* r;      // [frames][n] hard received words (then lambda = +-l0 / +-l1), or null
     float l0, l1;          // already in the rule's LLR unit
@@ -89,10 +91,9 @@ template <int DC, int DV, int RULE, bool EARLY, int CPT>
 __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
     static_assert(CPT % 2 == 0 && kLdsVpt % 2 == 0, "checks and variables are processed in pairs");
     extern __shared__ __align__(16) float smem[];
-    float* msg = smem;                                   // [E]
-    float* lam = smem + p.E;                             // [n], by VN position
-    uint32_t* bits = reinterpret_cast<uint32_t*>(lam + p.n);  // [nw], by VN position
-    int* red = reinterpret_cast<int*>(bits + p.nw);      // syndrome accumulator
+    float* msg = smem;                                        // [E]
+    uint32_t* bits = reinterpret_cast<uint32_t*>(smem + p.E); // [nw], by VN position
+    int* red = reinterpret_cast<int*>(bits + p.nw);           // syndrome accumulator
     const int t = threadIdx.x, nt = blockDim.x;
     const long long frame = blockIdx.x;
     if (frame >= p.frames) return;
@@ -108,23 +109,28 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
             off[v][k] = lds_address(msgb + p.vn_off[(long long)(t + v * nt) * DV + k]);
             asm volatile("" : "+v"(off[v][k]));
         }
-    // channel LLRs of the frame -> LDS, in VN position order
-    if (p.llr) {
-        const float* src = p.llr + frame * p.n;
-        for (int q = t; q < p.n; q += nt) lam[q] = src[p.perm[q]] * p.scale;
-    } else {
-        const uint8_t* src = p.r + frame * p.n;
-        for (int q = t; q < p.n; q += nt) {
-            const int j = p.perm[q];
-            const float mag = (j < p.g_length) ? p.l0 : p.l1;  // LogDecoder.java:49-54
-            lam[q] = (src[j] == 0) ? mag : -mag;
-        }
-    }
+    // channel LLR of variable j of this frame (LogDecoder.java:49-54 for a hard received word); the
+    // frame's 16 KiB are read twice (once per edge, once per variable), the second time from cache
+    const float* src_llr = p.llr ? p.llr + frame * p.n : nullptr;
+    const uint8_t* src_r = p.r ? p.r + frame * p.n : nullptr;
+    auto lam_of = [&](int j) -> float {
+        if (src_llr) return src_llr[j] * p.scale;
+        const float mag = (j < p.g_length) ? p.l0 : p.l1;
+        return (src_r[j] == 0) ? mag : -mag;
+    };
     if (t == 0) *red = 0;
-    __syncthreads();
     // beta of the first iteration: lambda + the zero-initialised alpha (LogDecoder.java:57, :70-77)
-    for (int e = t; e < (int)p.E; e += nt) msg[p.edge_slot[e]] = lam[p.edge_pos[e]] + 0.0f;
+    for (int e = t; e < (int)p.E; e += nt) msg[p.edge_slot[e]] = lam_of(p.edge_col[e]) + 0.0f;
     __syncthreads();
+
+    // channel LLRs of this thread's own variables stay in registers for the whole decode
+    v2f vl[kLdsVpt / 2];
+#pragma unroll
+    for (int v = 0; v < kLdsVpt; v += 2) {
+        float a = lam_of(p.perm[t + v * nt]), b = lam_of(p.perm[t + (v + 1) * nt]);
+        asm volatile("" : "+v"(a), "+v"(b));  // loaded once, here
+        vl[v / 2] = v2f{a, b};
+    }
 
     int iters = p.max_iters, synd = 0;
     for (int it = 0; it < p.max_iters; ++it) {
@@ -140,8 +146,8 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
 #pragma unroll
         for (int q = 0; q < CPT / 2; ++q) {
             v2f* row = reinterpret_cast<v2f*>(msg + 2 * DC * (t + q * nt));
-            if constexpr (RULE == kCnTanhPair) {
-                cn_tanh_pair<v2f, DC>(x[q]);
+            if constexpr (RULE == kCnComplement) {
+                cn_complement<v2f, DC>(x[q]);
             } else {
                 float xa[DC], xb[DC];
 #pragma unroll
@@ -158,13 +164,11 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit
         // (all gathers are issued before any scatter: distinct variables never share a slot)
         const bool write_beta = EARLY || (it + 1 < p.max_iters);
-        v2f va[kLdsVpt / 2][DV], vl[kLdsVpt / 2];
+        v2f va[kLdsVpt / 2][DV];
 #pragma unroll
-        for (int v = 0; v < kLdsVpt; v += 2) {
+        for (int v = 0; v < kLdsVpt; v += 2)
 #pragma unroll
             for (int k = 0; k < DV; ++k) va[v / 2][k] = v2f{lds_load(off[v][k]), lds_load(off[v + 1][k])};
-            vl[v / 2] = v2f{lam[t + v * nt], lam[t + (v + 1) * nt]};
-        }
 #pragma unroll
         for (int v = 0; v < kLdsVpt; v += 2) {
             v2f g;
@@ -241,7 +245,7 @@ inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
     switch (l.rule) {
         case kCnMinSum: if (l.early) LDPC_LDS(kCnMinSum, true); else LDPC_LDS(kCnMinSum, false); break;
         case kCnSumProduct: if (l.early) LDPC_LDS(kCnSumProduct, true); else LDPC_LDS(kCnSumProduct, false); break;
-        default: if (l.early) LDPC_LDS(kCnTanhPair, true); else LDPC_LDS(kCnTanhPair, false); break;
+        default: if (l.early) LDPC_LDS(kCnComplement, true); else LDPC_LDS(kCnComplement, false); break;
     }
 #undef LDPC_LDS
     return hipGetLastError();

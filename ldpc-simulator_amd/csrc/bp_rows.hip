@@ -17,7 +17,7 @@ void launch_cn(const RowsLaunch& l, const RowsParams& p, dim3 grid, dim3 block, 
     switch (l.rule) {
         case kCnMinSum: LDPC_CN(kCnMinSum); break;
         case kCnSumProduct: LDPC_CN(kCnSumProduct); break;
-        default: LDPC_CN(kCnTanhPair); break;
+        default: LDPC_CN(kCnComplement); break;
     }
 #undef LDPC_CN
 }

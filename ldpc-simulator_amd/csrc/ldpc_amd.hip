@@ -252,7 +252,7 @@ int launch_bp(ldpc_amd_ctx* c, const BpParams& p, int fpl, bool early, int wpb, 
     BpLaunch l;
     l.fpl = fpl;
     l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
-             : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnTanhPair;
+             : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
     l.early = early;
     l.wps = fpl == 4 ? 2 : 4;  // 4 frames per lane need ~180 VGPRs to stay out of scratch
     if (const char* env = getenv("LDPC_AMD_WPS")) l.wps = atoi(env) == 2 ? 2 : 4;
@@ -282,12 +282,12 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         return LDPC_AMD_OK;
     }
     const bool early = early_term != 0;
-    // Frame-resident engine: regular code whose messages + LLRs fit twice into a CU's LDS.
+    // Frame-resident engine: regular code whose messages fit at least twice into a CU's LDS.
     {
         const bool shape = (c->reg_dc == 6 && c->reg_dv == 3) || (c->reg_dc == 8 && c->reg_dv == 2);
         // exact tiling: 8 variables and 8 m / n checks per thread, whole wavefronts
         const int nt = n / kLdsVpt;
-        const size_t lds_bytes = ((size_t)c->E + (size_t)n + (size_t)c->nw + 4) * sizeof(float);
+        const size_t lds_bytes = ((size_t)c->E + (size_t)c->nw + 4) * sizeof(float);
         bool use = shape && n % (kLdsVpt * 64) == 0 && nt <= 512 && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll;
         if (const char* env = getenv("LDPC_AMD_ENGINE")) {
             if (!strcmp(env, "stream")) use = false;
@@ -297,7 +297,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             LdsParams q{};
             q.m = c->m; q.n = n; q.nw = c->nw; q.E = c->E;
             q.perm = c->d_res; q.pos_of_var = q.perm + n; q.vn_off = q.pos_of_var + n;
-            q.edge_slot = q.vn_off + c->E; q.edge_pos = q.edge_slot + c->E;
+            q.edge_slot = q.vn_off + c->E; q.edge_pos = q.edge_slot + c->E; q.edge_col = c->d_edge_col;
             q.llr = src.kind == Src::Float ? src.llr : nullptr;
             q.r = src.kind == Src::Bsc ? src.r : nullptr;
             q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
@@ -306,7 +306,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             q.hard = d_hard; q.out_iters = d_iters; q.out_synd = d_synd;
             LdsLaunch l;
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
-                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnTanhPair;
+                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
             l.early = early; l.threads = nt; l.lds_bytes = lds_bytes; l.stream = s;
             while (c->ev.size() < 2) {
                 hipEvent_t e;
@@ -442,7 +442,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             RowsLaunch l;
             l.fpl = fpl == 4 ? 4 : 1;
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
-                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnTanhPair;
+                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
             l.chunks = chunks; l.wpb = wpb; l.lds_bytes = lds_bytes; l.stream = s;
             LDPC_HIP(c, bp_rows_run(l, q));
         } else if (int rc = launch_bp(c, p, fpl, early, wpb, lds_bytes, pipelined, s)) {
