@@ -140,7 +140,7 @@ __device__ __forceinline__ float signum(float x) { return (x > 0.0f) ? 1.0f : (x
 // 2 atanh(prod tanh(|beta_k|/2)) with every factor t_k represented by its complement
 // q_k = 1 - t_k = 2w/(1 + w), w = e^-|beta_k|, which is formed directly (no cancellation), and every
 // partial product P represented by ITS complement Q = 1 - P through
-//     Q(P t) = q + t Q          and          Q(P1 P2) = Q1 + (1 - Q1) Q2,
+//     Q(P t) = Q + q (1 - Q)          and          Q(P1 P2) = Q1 + (1 - Q1) Q2,
 // sums of non-negative terms only.  Then alpha = ln((1 + P)/(1 - P)) = ln(2 - Q) - ln Q keeps full
 // relative accuracy in fp32 where alpha is large (Q small: 1 - P is never formed from a value rounded
 // next to 1) and an absolute error of an ulp of 1 where alpha is small, over the whole range in which
@@ -217,15 +217,14 @@ template <class V, int D>
 __device__ __forceinline__ void cn_complement(V (&b)[D]) {
 #pragma clang fp contract(off)
     const V one = vsplat<V>(1.0f);
-    V q[D], t[D], sg[D], pq[D];
+    V q[D], sg[D], pq[D];
     V Q = vsplat<V>(0.0f), all = one;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         sg[k] = vsign1(b[k]);
         q[k] = tanh_complement<V>(b[k]);
-        t[k] = one - q[k];
         pq[k] = Q;
-        Q = vfma(Q, t[k], q[k]);
+        Q = vfma(q[k], one - Q, Q);
         all = all * sg[k];
     }
     V sQ = vsplat<V>(0.0f);
@@ -233,7 +232,7 @@ __device__ __forceinline__ void cn_complement(V (&b)[D]) {
     for (int k = D - 1; k >= 0; --k) {
         const V mag = atanh2_complement<V>(vfma(sQ, one - pq[k], pq[k]));
         b[k] = mag * (all * sg[k]);
-        sQ = vfma(sQ, t[k], q[k]);
+        sQ = vfma(q[k], one - sQ, sQ);
     }
 }
 
@@ -351,7 +350,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
             const float qk = tanh_complement<float>(b);
             st[k * 64] = __uint_as_float(__float_as_uint(qk) | sg);
             sp[k * 64] = __uint_as_float(__float_as_uint(Q) | psg);
-            Q = fmaf(Q, 1.0f - qk, qk);
+            Q = fmaf(qk, 1.0f - Q, Q);
             psg ^= sg;
         }
         float sQ = 0.0f;
@@ -361,7 +360,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
             const float qk = fabsf(sv), pq = fabsf(pv);
             const float mag = atanh2_complement<float>(fmaf(sQ, 1.0f - pq, pq));
             row[(long long)k * T] = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(pv) & 0x80000000u) ^ ssg);
-            sQ = fmaf(sQ, 1.0f - qk, qk);
+            sQ = fmaf(qk, 1.0f - sQ, sQ);
             ssg ^= __float_as_uint(sv) & 0x80000000u;
         }
     } else {

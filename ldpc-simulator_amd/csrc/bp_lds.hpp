@@ -88,7 +88,7 @@ __device__ __forceinline__ int lds_syndrome(const LdsParams& p, const uint32_t* 
 
 // CPT (even) checks and kLdsVpt variables per thread, exactly: m = CPT * blockDim.x, n = kLdsVpt * blockDim.x.
 template <int DC, int DV, int RULE, bool EARLY, int CPT>
-__global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
+__global__ void __launch_bounds__(512, 6) bp_lds_kernel(LdsParams p) {
     static_assert(CPT % 2 == 0 && kLdsVpt % 2 == 0, "checks and variables are processed in pairs");
     extern __shared__ __align__(16) float smem[];
     float* msg = smem;                                        // [E]
@@ -135,30 +135,25 @@ __global__ void __launch_bounds__(512, 4) bp_lds_kernel(LdsParams p) {
     int iters = p.max_iters, synd = 0;
     for (int it = 0; it < p.max_iters; ++it) {
         // check nodes: beta -> alpha in place, two checks per step in the halves of packed registers
-        // (all rows are read before any is written back: distinct checks never share a slot)
-        v2f x[CPT / 2][DC];
-#pragma unroll
-        for (int q = 0; q < CPT / 2; ++q) {
-            const v2f* row = reinterpret_cast<const v2f*>(msg + 2 * DC * (t + q * nt));
-#pragma unroll
-            for (int k = 0; k < DC; ++k) x[q][k] = row[k];
-        }
 #pragma unroll
         for (int q = 0; q < CPT / 2; ++q) {
             v2f* row = reinterpret_cast<v2f*>(msg + 2 * DC * (t + q * nt));
+            v2f x[DC];
+#pragma unroll
+            for (int k = 0; k < DC; ++k) x[k] = row[k];
             if constexpr (RULE == kCnComplement) {
-                cn_complement<v2f, DC>(x[q]);
+                cn_complement<v2f, DC>(x);
             } else {
                 float xa[DC], xb[DC];
 #pragma unroll
-                for (int k = 0; k < DC; ++k) { xa[k] = x[q][k].x; xb[k] = x[q][k].y; }
+                for (int k = 0; k < DC; ++k) { xa[k] = x[k].x; xb[k] = x[k].y; }
                 cn_compute1<DC, RULE>(xa);
                 cn_compute1<DC, RULE>(xb);
 #pragma unroll
-                for (int k = 0; k < DC; ++k) x[q][k] = v2f{xa[k], xb[k]};
+                for (int k = 0; k < DC; ++k) x[k] = v2f{xa[k], xb[k]};
             }
 #pragma unroll
-            for (int k = 0; k < DC; ++k) row[k] = x[q][k];
+            for (int k = 0; k < DC; ++k) row[k] = x[k];
         }
         __syncthreads();
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit
