@@ -195,11 +195,13 @@ constexpr float kBitsPerNat = 1.4426950408889634f;  // 1 / ln 2: scale of the ch
 
 // q = 1 - tanh(|beta| ln2 / 2), beta in bits; beta = 0 gives exactly 1, |beta| > 55 exactly 0.
 // |beta| is only ever a source modifier of the exp2 and of the comparison.
-template <class V>
+// SAT = false leaves the saturation test out: for callers that know |beta| <= 55 in every lane.
+template <class V, bool SAT = true>
 __device__ __forceinline__ V tanh_complement(V beta) {
 #pragma clang fp contract(off)
     const V x = vabs(beta);
-    const V w = vsel_gt(x, kDoubleTanhSaturation, vsplat<V>(0.0f), vexp2(-x));
+    V w = vexp2(-x);
+    if constexpr (SAT) w = vsel_gt(x, kDoubleTanhSaturation, vsplat<V>(0.0f), w);
     return w * vrcp(vfma(w, vsplat<V>(0.5f), vsplat<V>(0.5f)));
 }
 
@@ -213,7 +215,7 @@ __device__ __forceinline__ V atanh2_complement(V Q) {
 // beta[0..D) -> alpha[0..D) in place.  Products ascend over k like those of LogDecoder.java:86-91;
 // leave-one-out is (prefix of k) * (suffix of k).  The sign of alpha_k is the product of the other
 // members' signs, formed as (product of all) * (own): exact for factors of +-1.
-template <class V, int D>
+template <class V, int D, bool SAT = true>
 __device__ __forceinline__ void cn_complement(V (&b)[D]) {
 #pragma clang fp contract(off)
     const V one = vsplat<V>(1.0f);
@@ -222,7 +224,7 @@ __device__ __forceinline__ void cn_complement(V (&b)[D]) {
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         sg[k] = vsign1(b[k]);
-        q[k] = tanh_complement<V>(b[k]);
+        q[k] = tanh_complement<V, SAT>(b[k]);
         pq[k] = Q;
         Q = vfma(q[k], one - Q, Q);
         all = all * sg[k];
