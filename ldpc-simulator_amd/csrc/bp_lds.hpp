@@ -87,8 +87,10 @@ __device__ __forceinline__ int lds_syndrome(const LdsParams& p, const uint32_t* 
 }
 
 // CPT (even) checks and kLdsVpt variables per thread, exactly: m = CPT * blockDim.x, n = kLdsVpt * blockDim.x.
-template <int DC, int DV, int RULE, bool EARLY, int CPT>
-__global__ void __launch_bounds__(512, 6) bp_lds_kernel(LdsParams p) {
+// WPE = wavefronts per SIMD the register budget is set for: 6 (80 registers, three 8-wave workgroups
+// per CU) or 4 (128 registers, two).
+template <int DC, int DV, int RULE, bool EARLY, int CPT, int WPE>
+__global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
     static_assert(CPT % 2 == 0 && kLdsVpt % 2 == 0, "checks and variables are processed in pairs");
     extern __shared__ __align__(16) float smem[];
     float* msg = smem;                                        // [E]
@@ -227,6 +229,7 @@ __global__ void __launch_bounds__(512, 6) bp_lds_kernel(LdsParams p) {
 struct LdsLaunch {
     int rule;
     bool early;
+    int wpe;  // 4 or 6, see bp_lds_kernel
     int threads;
     size_t lds_bytes;
     hipStream_t stream;
@@ -235,19 +238,24 @@ struct LdsLaunch {
 template <int DC, int DV, int CPT>
 inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
     const dim3 grid((unsigned)p.frames), block((unsigned)l.threads);
-#define LDPC_LDS(R, E)                                                                                       \
+#define LDPC_LDS2(R, E, W)                                                                                   \
     do {                                                                                                     \
-        auto k = bp_lds_kernel<DC, DV, R, E, CPT>;                                                                \
+        auto k = bp_lds_kernel<DC, DV, R, E, CPT, W>;                                                        \
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                            (int)l.lds_bytes);                                                \
         if (e != hipSuccess) return e;                                                                       \
         hipLaunchKernelGGL(k, grid, block, l.lds_bytes, l.stream, p);                                        \
+    } while (0)
+#define LDPC_LDS(R, E)                                                                                       \
+    do {                                                                                                     \
+        if (l.wpe >= 6) LDPC_LDS2(R, E, 6); else LDPC_LDS2(R, E, 4);                                         \
     } while (0)
     switch (l.rule) {
         case kCnMinSum: if (l.early) LDPC_LDS(kCnMinSum, true); else LDPC_LDS(kCnMinSum, false); break;
         case kCnSumProduct: if (l.early) LDPC_LDS(kCnSumProduct, true); else LDPC_LDS(kCnSumProduct, false); break;
         default: if (l.early) LDPC_LDS(kCnComplement, true); else LDPC_LDS(kCnComplement, false); break;
     }
+#undef LDPC_LDS2
 #undef LDPC_LDS
     return hipGetLastError();
 }

@@ -308,6 +308,10 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
                      : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
             l.early = early; l.threads = nt; l.lds_bytes = lds_bytes; l.stream = s;
+            // measured: three workgroups per CU pay off only for the fixed-iteration (6,3) kernel; every
+            // other variant loses more to register spills at 80 registers than it gains in occupancy
+            l.wpe = (!early && c->reg_dc == 6) ? 6 : 4;
+            if (const char* env = getenv("LDPC_AMD_LDS_WPE")) l.wpe = atoi(env);
             while (c->ev.size() < 2) {
                 hipEvent_t e;
                 LDPC_HIP(c, hipEventCreate(&e));
