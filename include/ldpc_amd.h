@@ -42,9 +42,9 @@ extern "C" {
 #define LDPC_AMD_ELIMIT (-5)  /* the code exceeds a compiled-in limit (node degree) */
 
 /* check-node rule */
-#define LDPC_AMD_CN_SUMPRODUCT 0 /* 2*atanh(prod tanh(beta/2)), LogDecoder.java:82-95, evaluated as
-                                    sign * phi(sum phi(|beta|)), phi(x) = -ln tanh(x/2): the same
-                                    function, formed so that fp32 stays accurate where double does */
+#define LDPC_AMD_CN_SUMPRODUCT 0 /* 2*atanh(prod tanh(beta/2)), LogDecoder.java:82-95, evaluated on the
+                                    complements 1 - tanh and 1 - prod: the same function, formed
+                                    so that fp32 stays accurate where double does */
 #define LDPC_AMD_CN_MINSUM 1     /* 0.7 * prod sign * min|beta|, MinSumDecoder.java:76-94 */
 #define LDPC_AMD_CN_SUMPRODUCT_TANH 2 /* the literal fp32 tanh product / atanh of LogDecoder.java:82-95;
                                          saturates at |beta| ~ 17 instead of the reference's ~ 38 */

@@ -12,7 +12,7 @@ namespace ldpc {
 // the layout in which lane t of a wave reads its own frame with one coalesced row per j.
 // A 64 x 64 block goes through LDS (row stride 65 words, conflict-free both ways).
 // `scale` converts the caller's natural-log LLRs into the unit the check-node rule works in
-// (1/ln 2 for the log-tanh rule, 1 otherwise); decisions depend on signs only.
+// (1/ln 2 for the default sum-product rule, 1 otherwise); decisions depend on signs only.
 struct FloatLlr {
     const float* in;
     float scale;

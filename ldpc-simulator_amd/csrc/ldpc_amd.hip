@@ -242,7 +242,7 @@ struct SrcArgs {
     double l0, l1;  // BSC magnitudes in nats, double as the reference forms them
 };
 
-// LLR unit of the selected check-node rule (see bp_kernels.hpp): bits for log-tanh, nats otherwise.
+// LLR unit of the selected check-node rule (see bp_kernels.hpp): bits for the default sum-product rule, nats otherwise.
 double llr_scale(const ldpc_amd_ctx* c) {
     return (c->cn_rule == LDPC_AMD_CN_MINSUM || c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH) ? 1.0 : 1.4426950408889634;
 }

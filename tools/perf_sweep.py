@@ -19,7 +19,7 @@ d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
 b_frame = iters * (4 * dec.E * 4 + n * 4)
 variants = [tuple(v.split(":")) for v in os.environ.get("SWEEP_VARIANTS", "0:4:2:0:stream,0:4:2:0:lds,2:4:2:0:lds,1:4:2:0:lds").split(",")]
-names = {0: "logtanh", 1: "minsum", 2: "tanh"}
+names = {0: "complement", 1: "minsum", 2: "tanh"}
 res = {}
 for r in range(rounds):
     for rule, fpl, wps, skip, eng in variants:
