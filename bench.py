@@ -99,6 +99,12 @@ def main():
                     help="skip the extra single-step measurement of the streaming engine (N=1 only)")
     args = ap.parse_args()
 
+    # Only the JSON line may appear on stdout: libraries underneath (RCCL prints a version banner at
+    # init) write there too, so everything else goes to stderr while the run lasts.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -111,7 +117,9 @@ def main():
         raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LDPC_BENCH_FORCE_DIST=1 initialises the process group also for a single rank (to rehearse the RCCL path)
+    use_dist = world > 1 or (os.environ.get("LDPC_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     import ldpc_simulator_amd as L
@@ -139,7 +147,7 @@ def main():
         d_cnt.zero_()
         dec.decode_batch_dev(d_llr.data_ptr(), F, iters, False, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr(), stream)
         dec.count_errors_dev(F, d_hard.data_ptr(), 0, d_it.data_ptr(), d_sw.data_ptr(), iters, d_cnt.data_ptr(), stream)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(d_cnt)  # the only exchange: error counters (RCCL)
         if timed:
             nl, ms, _ = dec.last_decode_timing()  # HIP events on `stream` around the message-passing kernel
@@ -148,17 +156,17 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -233,8 +241,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(code, args.ebn0, iters, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.destroy_process_group()
 
 
