@@ -5,6 +5,7 @@ error rate) leg on the GPU, write the H files and the result table.
                              with decoder="LogDecoderBefore" the *Before variant (all-bit BSC, uniform
                              LLRs; LDPC_QCIntBefore.java:104-123), with "MinSumDecoder" the sequential
                              min-sum driver (LDPC_GallagerLoopSimu.java:85-105)
+  qc_int_stream_simu         LDPC_QCIntStreamSimu.java:10-293 / LDPC_QCIntBefore.java (random QC codes)
   load_int_stream            LDPC_LoadIntStream.java:10-276 / LDPC_LoadIntBefore.java: H read from
                              `<name>-HMatrix.txt`, one table
 
@@ -62,16 +63,16 @@ def _legs(H, e_values, num_frames, max_l, decoder, seed, device, random_codeword
     return counters, minutes
 
 
-def gallager_int_stream_simu(file_name, n=1024, wr=8, wc=2, max_l=50, num_frames=10_000, num_cm=25,
-                             e_values=E_VALUES, decoder="LogDecoder", seed=1, out_dir=".", encoding="utf-8",
-                             device=-1, random_codewords=True, reduce_device=None):
-    """Returns counters[num_cm][len(e_values)]; writes `<file_name><i>-HMatrix.txt` and
-    `<file_name>-result.csv` into out_dir (rank 0)."""
+def _multi_matrix(file_name, make_code, n, label_wr, label_wc, max_l, num_frames, num_cm, e_values, decoder, seed,
+                  out_dir, encoding, device, random_codewords, reduce_device):
+    """The loop over parity-check matrices shared by the Gallager and QC mains (:55-218) and the table."""
     rank, _ = _rank_world()
     all_counters, totals, decodes = [], [], []
+    m = None
     for column in range(num_cm):
         t0 = time.perf_counter()
-        m, n_, rows, cols = codes.gallager(n, wr, wc, seed=int(seed) + column)   # same H on every rank
+        m, n_, rows, cols = make_code(column)                                    # same H on every rank
+        assert n_ == n
         if rank == 0:
             check_matrix_io.save_check_matrix(os.path.join(out_dir, "%s%d-HMatrix.txt" % (file_name, column)),
                                               m, n_, rows, cols)                 # :70-71
@@ -82,10 +83,30 @@ def gallager_int_stream_simu(file_name, n=1024, wr=8, wc=2, max_l=50, num_frames
         decodes.append(mins)
         totals.append((time.perf_counter() - t0) / 60.0)
     if rank == 0:
-        result_csv.write_result_csv(os.path.join(out_dir, file_name + "-result.csv"), n, wr, wc, max_l, num_frames,
-                                    list(e_values), all_counters, m=(n * wc) // wr, total_minutes=totals,
+        result_csv.write_result_csv(os.path.join(out_dir, file_name + "-result.csv"), n, label_wr, label_wc, max_l,
+                                    num_frames, list(e_values), all_counters, m=m, total_minutes=totals,
                                     decode_minutes=decodes, encoding=encoding)
     return all_counters
+
+
+def gallager_int_stream_simu(file_name, n=1024, wr=8, wc=2, max_l=50, num_frames=10_000, num_cm=25,
+                             e_values=E_VALUES, decoder="LogDecoder", seed=1, out_dir=".", encoding="utf-8",
+                             device=-1, random_codewords=True, reduce_device=None):
+    """Returns counters[num_cm][len(e_values)]; writes `<file_name><i>-HMatrix.txt` and
+    `<file_name>-result.csv` into out_dir (rank 0)."""
+    return _multi_matrix(file_name, lambda column: codes.gallager(n, wr, wc, seed=int(seed) + column), n, wr, wc,
+                         max_l, num_frames, num_cm, e_values, decoder, seed, out_dir, encoding, device,
+                         random_codewords, reduce_device)
+
+
+def qc_int_stream_simu(file_name, z=108, mb=5, nb=10, max_l=50, num_frames=10_000, num_cm=25, e_values=E_VALUES,
+                       decoder="LogDecoder", seed=1, out_dir=".", encoding="utf-8", device=-1,
+                       random_codewords=True, reduce_device=None):
+    """LDPC_QCIntStreamSimu.java:10-293 / LDPC_QCIntBefore.java: random quasi-cyclic codes by
+    GenerateMatrix.generateQC's rules (:91-153); the table's weight columns hold nb and mb (:238-239)."""
+    return _multi_matrix(file_name, lambda column: codes.random_qc(z, mb, nb, seed=int(seed) + column)[1], nb * z,
+                         nb, mb, max_l, num_frames, num_cm, e_values, decoder, seed, out_dir, encoding, device,
+                         random_codewords, reduce_device)
 
 
 def load_int_stream(file_name, wr, wc, max_l=50, num_frames=10_000, e_values=E_VALUES, decoder="LogDecoder", seed=1,

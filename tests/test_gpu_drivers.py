@@ -34,6 +34,21 @@ def test_gallager_int_stream_simu(pkg, oracle, tmp_path, decoder):
     assert cnt[0][1][1] > 0                                                      # the noisy legs do fail
 
 
+def test_qc_int_stream_simu(pkg, oracle, tmp_path):
+    z, mb, nb, L, F = 16, 3, 6, 15, 400
+    cnt = pkg.drivers.qc_int_stream_simu("qc", z=z, mb=mb, nb=nb, max_l=L, num_frames=F, num_cm=1, e_values=(0.03,),
+                                         decoder="LogDecoderBefore", seed=2, out_dir=str(tmp_path))
+    lines = (tmp_path / "qc-result.csv").read_text(encoding="utf-8").split("\n")
+    assert lines[1].startswith("%d,%d,%d,0.500000,%d,%d," % (nb * z, nb, mb, L, F))
+    m, n, rr, cc = pkg.check_matrix_io.load_check_matrix(str(tmp_path / "qc0-HMatrix.txt"))
+    base, (mm, nn, r0, c0) = pkg.codes.random_qc(z, mb, nb, seed=2)
+    assert (m, n) == (mb * z, nb * z) and (rr == r0).all() and (cc == c0).all()
+    eh, eg = pkg.encoder.systematic_pair(pkg.check_matrix_io.to_dense(m, n, rr, cc))
+    want = oracle.Graph(m, n, *np.nonzero(eh)).simulate(1, 0.03, (((2 << 16) + 0) << 8) + 0, 0, F, L, G=eg)
+    c = cnt[0][0]
+    assert c[0] == F and c[10] == want[10] and abs(int(c[1]) - int(want[1])) <= 3, (c[:12], want[:12])
+
+
 def test_load_int_stream(pkg, tmp_path):
     m, n, r, c = pkg.codes.gallager(512, 8, 2, seed=3)
     pkg.check_matrix_io.save_check_matrix(str(tmp_path / "code-HMatrix.txt"), m, n, r, c)
