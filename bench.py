@@ -83,6 +83,30 @@ def measured_traffic(kernel_prefix, frames, iters, n):
     return best
 
 
+def measured_issue_rates(kernel_prefix):
+    """VALU and LDS busy fractions of the kernel from the committed SQ counter summary
+    (profiles/<round>/*_sq_counters_*.txt, collected by tools/pmc_lds.sh): SQ_ACTIVE_INST_VALU counts
+    4-cycle units per SIMD (1024 SIMDs), SQ_LDS_IDX_ACTIVE LDS cycles per CU (256), GRBM_GUI_ACTIVE is
+    summed over the 8 XCDs."""
+    import glob
+    import re
+    out = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_sq_counters_*.txt"))):
+        vals = {}
+        try:
+            for line in open(path):
+                m = re.match(r".*(%s).*\s(SQ_\w+|GRBM_\w+)\s+(?:n=\d+\s+)?([0-9.e+]+)\s*$" % kernel_prefix, line)
+                if m:
+                    vals[m.group(2)] = float(m.group(3))
+        except OSError:
+            continue
+        if {"SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"} <= set(vals):
+            cycles = vals["GRBM_GUI_ACTIVE"] / 8.0
+            out = {"valu_busy": vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024.0),
+                   "lds_busy": vals["SQ_LDS_IDX_ACTIVE"] / (cycles * 256.0), "source": os.path.relpath(path, ROOT)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,6 +239,7 @@ def main():
                      "frame-major streaming kernel: HBM-bound"),
             "launch_ms": launch_s * 1e3,
             "algorithmic_bytes_per_launch": frames_per_launch * b_frame,
+            "issue": measured_issue_rates(kernel) if kernel == "bp_lds_kernel" else None,
         },
         "frame_error_rate": float(cnt[1]) / max(float(cnt[0]), 1.0),
     }
