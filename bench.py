@@ -65,6 +65,26 @@ def cpu_baseline(code, ebn0_db, iters, budget_s):
     }
 
 
+def cpu_baseline_dense(code, iters, threads):
+    """The reference's own cost model on the same code: per-frame dense alpha[m][n] / beta[n][m], adjacency
+    scan per call, d(d-1) tanh per check, dense syndrome (LogDecoder.java:17-123 line by line), on a few
+    frames of a BSC at e = 0.12 (no frame converges, so every frame runs all iterations)."""
+    from oracle import oracle_capi as oc
+
+    import ldpc_simulator_amd as L
+
+    m, n, rows, cols = code
+    H = L.check_matrix_io.to_dense(m, n, rows, cols)
+    frames = 2 * threads
+    rx = oc.gen_bsc(m, n, 1, 0.12, 0x5EED, 0, frames)
+    t0 = time.perf_counter()
+    _, it, _ = oc.logdecoder_dense_batch(H, rx, 0.12, iters, llr_mode=0, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": frames * (n - m) / dt / 1e9, "unit": "Gbit/s", "cores": threads, "kind": "port",
+            "sample": "%d frames, dense line-by-line mode of the reference's decode(), mean %.1f iterations, %.1f s"
+                      % (frames, float(it.mean()), dt)}
+
+
 def measured_traffic(kernel_prefix, frames, iters, n):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
     (profiles/<round>/*hbm_traffic.json; FETCH_SIZE and WRITE_SIZE collected in separate passes,
@@ -264,6 +284,7 @@ def main():
     if rank == 0:
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(code, args.ebn0, iters, args.cpu_seconds)
+            out["cpu_baseline_dense"] = cpu_baseline_dense(code, iters, out["cpu_baseline"]["cores"])
         else:
             out["cpu_baseline"] = None
         sys.stdout.flush()
