@@ -9,11 +9,11 @@ namespace ldpc {
 
 namespace {
 
-template <int FPL>
+template <int FPL, int DC>
 void launch_cn(const RowsLaunch& l, const RowsParams& p, dim3 grid, dim3 block, bool first) {
 #define LDPC_CN(R)                                                                                          \
-    if (first) hipLaunchKernelGGL((rows_cn_kernel<FPL, R, true>), grid, block, l.lds_bytes, l.stream, p);   \
-    else       hipLaunchKernelGGL((rows_cn_kernel<FPL, R, false>), grid, block, l.lds_bytes, l.stream, p)
+    if (first) hipLaunchKernelGGL((rows_cn_kernel<FPL, R, true, DC>), grid, block, l.lds_bytes, l.stream, p);   \
+    else       hipLaunchKernelGGL((rows_cn_kernel<FPL, R, false, DC>), grid, block, l.lds_bytes, l.stream, p)
     switch (l.rule) {
         case kCnMinSum: LDPC_CN(kCnMinSum); break;
         case kCnSumProduct: LDPC_CN(kCnSumProduct); break;
@@ -22,7 +22,7 @@ void launch_cn(const RowsLaunch& l, const RowsParams& p, dim3 grid, dim3 block, 
 #undef LDPC_CN
 }
 
-template <int FPL>
+template <int FPL, int DC, int DV>
 hipError_t run(const RowsLaunch& l, RowsParams p) {
     const dim3 block((unsigned)(64 * l.wpb));
     const dim3 grid((unsigned)((l.chunks + l.wpb - 1) / l.wpb), (unsigned)p.b.tiles);
@@ -31,8 +31,8 @@ hipError_t run(const RowsLaunch& l, RowsParams p) {
     for (int it = 0; it < p.b.max_iters; ++it) {
         p.iter = it;
         const bool last = it + 1 == p.b.max_iters;
-        launch_cn<FPL>(l, p, grid, block, it == 0);
-        hipLaunchKernelGGL((rows_vn_kernel<FPL>), grid, block, l.lds_bytes, l.stream, p, (p.early || !last) ? 1 : 0);
+        launch_cn<FPL, DC>(l, p, grid, block, it == 0);
+        hipLaunchKernelGGL((rows_vn_kernel<FPL, DV>), grid, block, l.lds_bytes, l.stream, p, (p.early || !last) ? 1 : 0);
         if (p.early || last) {
             hipLaunchKernelGGL((rows_synd_kernel<FPL>), grid, block, 0, l.stream, p);
             hipLaunchKernelGGL(rows_finish_kernel, sgrid, dim3(256), 0, l.stream, p, slots, last ? 1 : 0);
@@ -42,10 +42,17 @@ hipError_t run(const RowsLaunch& l, RowsParams p) {
     return hipGetLastError();
 }
 
+template <int DC, int DV>
+hipError_t run_fpl(const RowsLaunch& l, const RowsParams& p) {
+    return l.fpl == 4 ? run<4, DC, DV>(l, p) : run<1, DC, DV>(l, p);
+}
+
 }  // namespace
 
 hipError_t bp_rows_run(const RowsLaunch& l, RowsParams p) {
-    return l.fpl == 4 ? run<4>(l, p) : run<1>(l, p);
+    if (l.dc == 6 && l.dv == 3) return run_fpl<6, 3>(l, p);
+    if (l.dc == 8 && l.dv == 2) return run_fpl<8, 2>(l, p);
+    return run_fpl<0, 0>(l, p);
 }
 
 }  // namespace ldpc

@@ -36,7 +36,15 @@ __device__ __forceinline__ bool rows_lane_active(const RowsParams& p, int tile, 
     return true;
 }
 
-template <int FPL, int RULE, bool FIRST>
+// Regular codes (DC / DV > 0 = the degree of every check / variable): a wave's rows are handled in
+// groups whose loads are all issued before the first of them is used, so that a small batch, where a
+// launch is a few thousand short waves and nothing else hides the memory latency, waits once per
+// group instead of once per row.  Same per-row arithmetic, same bits.
+template <int FPL, int D> constexpr int rows_group() {  // at most 48 message registers in flight
+    return 48 / (D * FPL) >= 4 ? 4 : 48 / (D * FPL) >= 1 ? 48 / (D * FPL) : 1;
+}
+
+template <int FPL, int RULE, bool FIRST, int DC>
 __global__ void __launch_bounds__(256, 4) rows_cn_kernel(RowsParams p) {
     extern __shared__ float lds_all[];
     float* lds = lds_all + (long long)(threadIdx.x >> 6) * 2 * p.b.lds_maxd * 64;
@@ -49,16 +57,29 @@ __global__ void __launch_bounds__(256, 4) rows_cn_kernel(RowsParams p) {
     float* msg = p.b.ws_msg + (long long)tile * p.b.msg_tile + lane * FPL;
     const float* lam = p.b.ws_lam + (long long)tile * p.b.lam_tile + lane * FPL;
     if (rows_lane_active<FPL>(p, tile, lane)) {
-        for (int i = i0; i < i1; ++i) {
-            const int e0 = p.b.row_ptr[i];
-            const int d = p.b.row_ptr[i + 1] - e0;
-            cn_dispatch<FPL, RULE, FIRST>(d, msg + (long long)e0 * p.b.msg_row, lam, p.b.edge_col + e0, p.b.msg_row,
-                                          p.b.lam_row, lds, p.b.lds_maxd, lane);
+        if constexpr (DC > 0) {
+            constexpr int G = rows_group<FPL, DC>();
+            for (int i = i0; i < i1; i += G) {
+                float buf[G][DC][FPL];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (i + g < i1) cn_load<FPL, DC, FIRST>(p.b, msg, lam, i + g, buf[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (i + g < i1) cn_finish<FPL, DC, RULE, FIRST>(p.b, msg, i + g, buf[g]);
+            }
+        } else {
+            for (int i = i0; i < i1; ++i) {
+                const int e0 = p.b.row_ptr[i];
+                const int d = p.b.row_ptr[i + 1] - e0;
+                cn_dispatch<FPL, RULE, FIRST>(d, msg + (long long)e0 * p.b.msg_row, lam, p.b.edge_col + e0, p.b.msg_row,
+                                              p.b.lam_row, lds, p.b.lds_maxd, lane);
+            }
         }
     }
 }
 
-template <int FPL>
+template <int FPL, int DV>
 __global__ void __launch_bounds__(256, 4) rows_vn_kernel(RowsParams p, int write_beta) {
     extern __shared__ float lds_all[];
     float* lds = lds_all + (long long)(threadIdx.x >> 6) * 2 * p.b.lds_maxd * 64;
@@ -75,6 +96,19 @@ __global__ void __launch_bounds__(256, 4) rows_vn_kernel(RowsParams p, int write
     uint32_t acc[FPL];
 #pragma unroll
     for (int f = 0; f < FPL; ++f) acc[f] = 0u;
+    if constexpr (DV > 0) {
+        constexpr int G = rows_group<FPL, DV>();
+        for (int j = j0; j < j1; j += G) {
+            VnBuf<FPL, DV> buf[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (j + g < j1) vn_load<FPL, DV>(p.b, msg, lam, j + g, buf[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (j + g < j1) vn_finish<FPL, DV>(p.b, msg, bits, j + g, write_beta != 0, buf[g], acc);
+        }
+        return;
+    }
     for (int j = j0; j < j1; ++j) {
         const int c0 = p.b.col_ptr[j];
         const int d = p.b.col_ptr[j + 1] - c0;
@@ -154,6 +188,7 @@ __global__ void __launch_bounds__(256) rows_export_kernel(RowsParams p, int slot
 constexpr int kRowsRegDegCn = 20, kRowsRegDegVn = 32;  // register limits of the kernels in bp_rows.hip
 
 struct RowsLaunch {
+    int dc, dv;         // degrees of a regular code the kernels are specialised for, else 0, 0
     int fpl;            // 1 or 4
     int rule;
     int chunks;         // row / variable chunks per tile

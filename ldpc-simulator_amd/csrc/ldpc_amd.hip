@@ -445,6 +445,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             LDPC_HIP(c, hipMemsetAsync(ws_state, 0, 4 * slots * sizeof(int32_t), s));
             RowsLaunch l;
             l.fpl = fpl == 4 ? 4 : 1;
+            l.dc = c->reg_dc; l.dv = c->reg_dv;  // 0 for an irregular code
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
                      : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
             l.chunks = chunks; l.wpb = wpb; l.lds_bytes = lds_bytes; l.stream = s;
