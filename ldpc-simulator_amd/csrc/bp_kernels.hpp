@@ -141,12 +141,12 @@ __device__ __forceinline__ float signum(float x) { return (x > 0.0f) ? 1.0f : (x
 // q_k = 1 - t_k = 2w/(1 + w), w = e^-|beta_k|, which is formed directly (no cancellation), and every
 // partial product P represented by ITS complement Q = 1 - P through
 //     Q(P t) = Q + q (1 - Q)          and          Q(P1 P2) = Q1 + (1 - Q1) Q2,
-// sums of non-negative terms only.  Then alpha = ln((1 + P)/(1 - P)) = ln(2 - Q) - ln Q keeps full
+// sums of non-negative terms only.  Then alpha = ln((1 + P)/(1 - P)) = ln(2/Q - 1) keeps full
 // relative accuracy in fp32 where alpha is large (Q small: 1 - P is never formed from a value rounded
 // next to 1) and an absolute error of an ulp of 1 where alpha is small, over the whole range in which
 // the double-precision reference is finite.  Q = 0 (every other member saturated) gives +Inf; a
 // member with beta = 0 has q = 1, which makes Q exactly 1 and alpha exactly 0; NaN stays NaN.
-// Per edge this costs exp2, rcp and two log2.
+// Per edge this costs exp2, two rcp and log2.
 //
 // Everything below is written once for V = float and V = v2f (two independent checks per lane): on
 // gfx950 a plain fp32 VALU instruction and a packed one (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
@@ -185,7 +185,7 @@ template <> __device__ __forceinline__ float vsplat<float>(float x) { return x; 
 template <> __device__ __forceinline__ v2f vsplat<v2f>(float x) { return v2f{x, x}; }
 
 // Units: with this rule every LLR and message is held in BITS (natural-log value / ln 2; the layout
-// kernels scale the channel LLRs once on the way in, decisions only need signs).  Then w = 2^-x is
+// kernels scale the channel LLRs once on the way in, decisions only need signs).  Then 2^|x| is
 // the bare hardware exp2 and alpha comes straight out of the hardware log2, with no constants.
 //
 // |beta| above 55 ln 2 nats = 55 bits has tanh(beta/2) == 1.0 in double (1 - tanh < 2^-54): the
@@ -193,23 +193,25 @@ template <> __device__ __forceinline__ v2f vsplat<v2f>(float x) { return v2f{x, 
 constexpr float kDoubleTanhSaturation = 55.0f;   // bits
 constexpr float kBitsPerNat = 1.4426950408889634f;  // 1 / ln 2: scale of the channel LLRs for this rule
 
-// q = 1 - tanh(|beta| ln2 / 2), beta in bits; beta = 0 gives exactly 1, |beta| > 55 exactly 0.
-// |beta| is only ever a source modifier of the exp2 and of the comparison.
-// SAT = false leaves the saturation test out: for callers that know |beta| <= 55 in every lane.
+// q = 1 - tanh(|beta| ln2 / 2) = 2 / (2^|beta| + 1), beta in bits; beta = 0 gives exactly 1,
+// |beta| > 55 (and an overflowing 2^|beta|) exactly 0.  |beta| is only ever a source modifier of the
+// exp2 and of the comparison.  SAT = false leaves the saturation test out: for callers that know
+// |beta| <= 55 in every lane.
 template <class V, bool SAT = true>
 __device__ __forceinline__ V tanh_complement(V beta) {
 #pragma clang fp contract(off)
     const V x = vabs(beta);
-    V w = vexp2(-x);
-    if constexpr (SAT) w = vsel_gt(x, kDoubleTanhSaturation, vsplat<V>(0.0f), w);
-    return w * vrcp(vfma(w, vsplat<V>(0.5f), vsplat<V>(0.5f)));
+    V e = vexp2(x);
+    if constexpr (SAT) e = vsel_gt(x, kDoubleTanhSaturation, vsplat<V>(__builtin_inff()), e);
+    return vrcp(vfma(e, vsplat<V>(0.5f), vsplat<V>(0.5f)));
 }
 
-// |alpha| in bits from the complement Q of a leave-one-out product
+// |alpha| in bits from the complement Q of a leave-one-out product: log2((2 - Q)/Q) = log2(2/Q - 1).
+// Q = 1 gives exactly 0, Q = 0 gives +Inf.
 template <class V>
 __device__ __forceinline__ V atanh2_complement(V Q) {
 #pragma clang fp contract(off)
-    return vlog2(vsplat<V>(2.0f) - Q) - vlog2(Q);
+    return vlog2(vfma(vrcp(Q), vsplat<V>(2.0f), vsplat<V>(-1.0f)));
 }
 
 // beta[0..D) -> alpha[0..D) in place.  Products ascend over k like those of LogDecoder.java:86-91;
