@@ -189,21 +189,21 @@ template <> __device__ __forceinline__ v2f vsplat<v2f>(float x) { return v2f{x, 
 // the bare hardware exp2 and alpha comes straight out of the hardware log2, with no constants.
 //
 // |beta| above 55 ln 2 nats = 55 bits has tanh(beta/2) == 1.0 in double (1 - tanh < 2^-54): the
-// reference's factor is exactly 1 there, so q is exactly 0 (a select on the argument: no branch).
+// reference's factor is exactly 1 there, so q is exactly 0.
 constexpr float kDoubleTanhSaturation = 55.0f;   // bits
 constexpr float kBitsPerNat = 1.4426950408889634f;  // 1 / ln 2: scale of the channel LLRs for this rule
 
-// q = 1 - tanh(|beta| ln2 / 2) = 2 / (2^|beta| + 1), beta in bits; beta = 0 gives exactly 1,
-// |beta| > 55 (and an overflowing 2^|beta|) exactly 0.  |beta| is only ever a source modifier of the
-// exp2 and of the comparison.  SAT = false leaves the saturation test out: for callers that know
-// |beta| <= 55 in every lane.
-template <class V, bool SAT = true>
+// q = 1 - tanh(|beta| ln2 / 2) = 2 / (2^|beta| + 1), beta in bits; beta = 0 gives exactly 1.
+// Saturation costs one multiplication: 2^|beta| is carried scaled by 2^73, which overflows to +Inf
+// from |beta| = 55 on, and 1/Inf is the exact 0 the reference's factor of exactly 1 stands for; below
+// the threshold the scaling is undone exactly inside the fused multiply-add.  |beta| is a source
+// modifier of the exp2.
+template <class V>
 __device__ __forceinline__ V tanh_complement(V beta) {
 #pragma clang fp contract(off)
-    const V x = vabs(beta);
-    V e = vexp2(x);
-    if constexpr (SAT) e = vsel_gt(x, kDoubleTanhSaturation, vsplat<V>(__builtin_inff()), e);
-    return vrcp(vfma(e, vsplat<V>(0.5f), vsplat<V>(0.5f)));
+    static_assert(kDoubleTanhSaturation == 55.0f, "2^73 * 2^55 = 2^128 is the first fp32 overflow");
+    const V e = vexp2(vabs(beta)) * vsplat<V>(9.4447329657392904e21f);             // 2^73
+    return vrcp(vfma(e, vsplat<V>(5.2939559203393771e-23f), vsplat<V>(0.5f)));     // 2^-74
 }
 
 // |alpha| in bits from the complement Q of a leave-one-out product: log2((2 - Q)/Q) = log2(2/Q - 1).
@@ -217,7 +217,7 @@ __device__ __forceinline__ V atanh2_complement(V Q) {
 // beta[0..D) -> alpha[0..D) in place.  Products ascend over k like those of LogDecoder.java:86-91;
 // leave-one-out is (prefix of k) * (suffix of k).  The sign of alpha_k is the product of the other
 // members' signs, formed as (product of all) * (own): exact for factors of +-1.
-template <class V, int D, bool SAT = true>
+template <class V, int D>
 __device__ __forceinline__ void cn_complement(V (&b)[D]) {
 #pragma clang fp contract(off)
     const V one = vsplat<V>(1.0f);
@@ -226,7 +226,7 @@ __device__ __forceinline__ void cn_complement(V (&b)[D]) {
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         sg[k] = vsign1(b[k]);
-        q[k] = tanh_complement<V, SAT>(b[k]);
+        q[k] = tanh_complement<V>(b[k]);
         pq[k] = Q;
         Q = vfma(q[k], one - Q, Q);
         all = all * sg[k];

@@ -144,13 +144,7 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
 #pragma unroll
             for (int k = 0; k < DC; ++k) x[k] = row[k];
             if constexpr (RULE == kCnComplement) {
-                // the saturation selects are only needed when some |beta| of the wave exceeds the
-                // threshold (a converged frame late in a long run); max ignores NaN, as the select does
-                float mx = fmaxf(fabsf(x[0].x), fabsf(x[0].y));
-#pragma unroll
-                for (int k = 1; k < DC; ++k) mx = fmaxf(mx, fmaxf(fabsf(x[k].x), fabsf(x[k].y)));
-                if (__ballot(mx > kDoubleTanhSaturation) != 0ull) cn_complement<v2f, DC, true>(x);
-                else cn_complement<v2f, DC, false>(x);
+                cn_complement<v2f, DC>(x);
             } else {
                 float xa[DC], xb[DC];
 #pragma unroll
