@@ -46,6 +46,24 @@ def simulate_sharded(simulate_fn, first_frame, frames, max_iters, rank=0, world=
     return allreduce_counters(local, device)
 
 
+def simulate_until(simulate_fn, max_iters, min_frame_errors=100, max_frames=10 ** 8, batch=1 << 20, first_frame=0,
+                   rank=0, world=1, device=None):
+    """One point of an error-rate curve: decode batches of `batch` frames (sharded over the ranks, global
+    frame indices first_frame, first_frame + 1, ...) until at least `min_frame_errors` frames have failed or
+    `max_frames` have been decoded, whichever comes first.  The counters are all-reduced after every batch,
+    so every rank takes the same decision to stop; the frames decoded, and so the result, do not depend on
+    the number of ranks.  Returns the summed counter vector."""
+    total = np.zeros(capi.CNT_FIXED + int(max_iters), np.uint64)
+    done = 0
+    while done < max_frames:
+        count = int(min(batch, max_frames - done))
+        total += simulate_sharded(simulate_fn, first_frame + done, count, max_iters, rank, world, device)
+        done += count
+        if int(total[capi.CNT_FRAME_ERRORS]) >= min_frame_errors:
+            break
+    return total
+
+
 def rates(counters, m, n):
     """FER / IFER / CFER / IBER / mean iterations as LDPC_GallagerIntStreamSimu.java:186-212
     derives them from the counters."""

@@ -129,6 +129,20 @@ total = L.sim.simulate_sharded(fn, 1000, 301, 20, rank, world)
 whole = g.simulate(oc.CH_BSC_ALL, 0.04, 5, 1000, 301, 20, threads=1)
 assert (total == whole).all(), (total, whole)
 assert total[0] == 301
+# stop rule of an error-rate point: same batches, same stop on every rank, same result as one rank
+calls = []
+def fn2(first, count):
+    calls.append((first, count))
+    return fn(first, count)
+until = L.sim.simulate_until(fn2, 20, min_frame_errors=12, max_frames=2000, batch=150, first_frame=40, rank=rank, world=world)
+alone, done = np.zeros_like(until), 0
+while done < 2000 and alone[1] < 12:
+    alone += g.simulate(oc.CH_BSC_ALL, 0.04, 5, 40 + done, 150, 20, threads=1)
+    done += 150
+assert (until == alone).all() and until[1] >= 12 and until[0] == done < 2000, (until[:3], alone[:3])
+assert len(calls) == done // 150 and all(c == 75 for _, c in calls)
+capped = L.sim.simulate_until(fn, 20, min_frame_errors=10 ** 9, max_frames=260, batch=100, rank=rank, world=world)
+assert capped[0] == 260
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """

@@ -106,3 +106,23 @@ def test_config3_ebn0_sweep_inside_oracle_confidence_intervals(pkg, oracle):
             io = want[8] / (want[0] - want[1])
             assert abs(ig - io) < 0.05 * io + 0.2
     print("Eb/N0, GPU FER, oracle FER, oracle 95% CI:", rows_out)
+
+
+def test_config3_stop_rule_on_the_gpu(pkg):
+    """One curve point the way config 3 runs it: batches until >= 100 frame errors or the frame budget is
+    spent (sim.simulate_until), on the (3,6) n = 4096 code with early termination."""
+    m, n, rows, cols = pkg.codes.regular_ldpc(4096, 3, 6, seed=1)
+    dec = pkg.Decoder(m, n, rows, cols)
+    L = 50
+
+    def point(ebn0, budget):
+        return pkg.sim.simulate_until(lambda first, count: dec.simulate(pkg.capi.CH_AWGN, ebn0, 11, first, count, L, True),
+                                      L, min_frame_errors=100, max_frames=budget, batch=1 << 14)
+
+    noisy = point(1.2, 1 << 18)          # waterfall: the first batch already holds > 100 failures
+    assert noisy[0] == 1 << 14 and noisy[1] >= 100
+    clean = point(2.2, 1 << 16)          # error floor far below 1/65536 here: the budget ends the run
+    assert clean[0] == 1 << 16 and clean[1] < 100
+    assert clean[16:].sum() == clean[0] and noisy[16:].sum() == noisy[0]     # every frame is in the histogram
+    r = pkg.sim.rates(noisy, m, n)
+    assert 0.05 < r["FER"] <= 1.0 and r["avg_iters_wrong"] == L
