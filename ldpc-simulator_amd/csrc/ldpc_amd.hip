@@ -42,12 +42,12 @@ struct ldpc_amd_ctx {
     size_t stage_bytes[4] = {0, 0, 0, 0};
     unsigned long long* d_counters = nullptr;
     size_t counters_len = 0;
-    // tables of the frame-resident engine (built on first use, see build_resident_tables)
     // generator matrix for random codewords: k rows packed 32 columns per word (null = all-zero word)
     int gen_k = 0;
     uint32_t* d_gen = nullptr;
     void* stage_cw = nullptr;
     size_t stage_cw_bytes = 0;
+    // tables of the frame-resident engine (built on first use, see build_resident_tables)
     int res_nt = 0;
     int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E] | edge_slot[E] | edge_pos[E]
     double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
@@ -55,7 +55,6 @@ struct ldpc_amd_ctx {
     std::vector<hipEvent_t> ev;
     int timed_launches = 0;
     long long timed_frames = 0;
-    hipStream_t timed_stream = nullptr;
     const char* last_kernel = "";  // which message-passing kernel the last decode ran
     std::string err;
 };
@@ -272,7 +271,6 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     if (frames < 0 || max_iters < 0 || !d_hard) return fail(c, LDPC_AMD_EINVAL, "decode: bad argument");
     c->timed_launches = 0;
     c->timed_frames = 0;
-    c->timed_stream = s;
     if (frames == 0) return LDPC_AMD_OK;
     const int n = c->n;
     if (max_iters == 0) {  // maxL = 0: all-zero word, 0 iterations, syndrome 0 (LogDecoder.java:61, :122)

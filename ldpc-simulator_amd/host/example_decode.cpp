@@ -1,7 +1,7 @@
 // Minimal C++ caller of the host mirror; mirrors the per-frame call of
 // LDPC_GallagerIntStreamSimu.java:122.
-//   g++ -std=c++17 -I. ldpc-simulator_amd/host/example_decode.cpp -L ldpc-simulator_amd -lldpc_amd \
-//       -Wl,-rpath,$PWD/ldpc-simulator_amd -o /tmp/example_decode
+//   g++ -std=c++17 ldpc-simulator_amd/host/example_decode.cpp -L ldpc-simulator_amd -lldpc_amd
+//       -Wl,-rpath,$PWD/ldpc-simulator_amd -o /tmp/example_decode      (one command line)
 #include <cstdio>
 
 #include "LogDecoder.hpp"
