@@ -38,8 +38,11 @@ struct ldpc_amd_ctx {
     size_t ws_bytes = 0;
     unsigned long long ws_limit = 0;
     // staging for the host-pointer entry points and for simulate
-    void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t stage_bytes[4] = {0, 0, 0, 0};
+    // (slots 4..7 are the second set of the double-buffered host-pointer path)
+    void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipStream_t io_stream[2] = {nullptr, nullptr};
+    hipEvent_t io_decoded[2] = {nullptr, nullptr};
     unsigned long long* d_counters = nullptr;
     size_t counters_len = 0;
     // generator matrix for random codewords: k rows packed 32 columns per word (null = all-zero word)
@@ -610,7 +613,12 @@ int ldpc_amd_destroy(ldpc_amd_ctx* c) {
         (void)hipDeviceSynchronize();
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
         void* ptrs[] = {c->d_row_ptr, c->d_edge_col, c->d_col_ptr, c->d_col_edge, c->ws, c->d_res,
-                        c->stage[0],  c->stage[1],   c->stage[2],  c->stage[3],   c->d_counters, c->d_gen,      c->stage_cw};
+                        c->stage[0],  c->stage[1],   c->stage[2],  c->stage[3],   c->d_counters, c->d_gen,      c->stage_cw,
+                        c->stage[4],  c->stage[5],   c->stage[6],  c->stage[7]};
+        for (int i = 0; i < 2; ++i) {
+            if (c->io_stream[i]) (void)hipStreamDestroy(c->io_stream[i]);
+            if (c->io_decoded[i]) (void)hipEventDestroy(c->io_decoded[i]);
+        }
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -674,7 +682,9 @@ int ldpc_amd_decode_bsc_batch_dev(ldpc_amd_ctx* c, const uint8_t* d_r, int64_t f
     return decode_dev(c, src, frames, max_iters, early_term, d_hard, d_iters, d_synd, (hipStream_t)stream);
 }
 
-// Host-pointer variants: stage a chunk of frames through device buffers.
+// Host-pointer variants: chunks of frames are staged through two sets of device buffers on two
+// streams, so that the copy in of chunk i + 1 and the copy out of chunk i - 1 run while chunk i is
+// decoded.  The decodes themselves stay in order (they share the decode workspace).
 static int decode_host(ldpc_amd_ctx* c, const void* in, size_t in_elem, bool bsc, double e, int llr_mode,
                        int64_t frames, int32_t max_iters, int32_t early_term, uint8_t* hard, int32_t* iters,
                        int32_t* synd) {
@@ -685,29 +695,49 @@ static int decode_host(ldpc_amd_ctx* c, const void* in, size_t in_elem, bool bsc
         if (int rc = bsc_magnitudes(c, e, llr_mode, &l0, &l1)) return rc;
     DeviceGuard guard(c->device);
     if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
-    const size_t n = (size_t)c->n;
-    const long long chunk = std::max<long long>(1, std::min<long long>(frames, (long long)((512ull << 20) / (n * 4))));
-    int launches = 0;
-    long long tframes = 0;
-    for (long long f0 = 0; f0 < frames; f0 += chunk) {
-        const long long nf = std::min<long long>(chunk, frames - f0);
-        if (int rc = ensure_stage(c, 0, (size_t)nf * n * in_elem)) return rc;
-        if (int rc = ensure_stage(c, 1, (size_t)nf * n)) return rc;
-        if (int rc = ensure_stage(c, 2, (size_t)nf * 4)) return rc;
-        if (int rc = ensure_stage(c, 3, (size_t)nf * 4)) return rc;
-        LDPC_HIP(c, hipMemcpy(c->stage[0], (const char*)in + (size_t)f0 * n * in_elem, (size_t)nf * n * in_elem,
-                              hipMemcpyHostToDevice));
-        SrcArgs src{bsc ? Src::Bsc : Src::Float, (const float*)c->stage[0], (const uint8_t*)c->stage[0], l0, l1};
-        if (int rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)c->stage[1], (int32_t*)c->stage[2],
-                                (int32_t*)c->stage[3], nullptr))
-            return rc;
-        LDPC_HIP(c, hipMemcpy(hard + (size_t)f0 * n, c->stage[1], (size_t)nf * n, hipMemcpyDeviceToHost));
-        if (iters) LDPC_HIP(c, hipMemcpy(iters + f0, c->stage[2], (size_t)nf * 4, hipMemcpyDeviceToHost));
-        if (synd) LDPC_HIP(c, hipMemcpy(synd + f0, c->stage[3], (size_t)nf * 4, hipMemcpyDeviceToHost));
-        launches += c->timed_launches;
-        tframes += c->timed_frames;
+    if (frames == 0) return LDPC_AMD_OK;
+    for (int i = 0; i < 2; ++i) {
+        if (!c->io_stream[i]) LDPC_HIP(c, hipStreamCreateWithFlags(&c->io_stream[i], hipStreamNonBlocking));
+        if (!c->io_decoded[i]) LDPC_HIP(c, hipEventCreateWithFlags(&c->io_decoded[i], hipEventDisableTiming));
     }
-    (void)launches; (void)tframes;
+    const size_t n = (size_t)c->n;
+    // about 64 MiB of input per chunk: long enough to keep the link busy, short enough to overlap
+    const long long chunk = std::max<long long>(256, (long long)((64ull << 20) / (n * in_elem)));
+    const long long chunks = (frames + chunk - 1) / chunk;
+    auto copy_out = [&](long long i) -> int {  // results of chunk i, on its stream
+        const int set = (int)(i & 1);
+        const long long f0 = i * chunk, nf = std::min<long long>(chunk, frames - f0);
+        void** st = c->stage + 4 * set;
+        hipStream_t s = c->io_stream[set];
+        LDPC_HIP(c, hipMemcpyAsync(hard + (size_t)f0 * n, st[1], (size_t)nf * n, hipMemcpyDeviceToHost, s));
+        if (iters) LDPC_HIP(c, hipMemcpyAsync(iters + f0, st[2], (size_t)nf * 4, hipMemcpyDeviceToHost, s));
+        if (synd) LDPC_HIP(c, hipMemcpyAsync(synd + f0, st[3], (size_t)nf * 4, hipMemcpyDeviceToHost, s));
+        return LDPC_AMD_OK;
+    };
+    for (long long i = 0; i < chunks; ++i) {
+        const int set = (int)(i & 1);
+        const long long f0 = i * chunk, nf = std::min<long long>(chunk, frames - f0);
+        hipStream_t s = c->io_stream[set];
+        LDPC_HIP(c, hipStreamSynchronize(s));  // chunk i - 2 has left this set's buffers
+        if (int rc = ensure_stage(c, 4 * set + 0, (size_t)nf * n * in_elem)) return rc;
+        if (int rc = ensure_stage(c, 4 * set + 1, (size_t)nf * n)) return rc;
+        if (int rc = ensure_stage(c, 4 * set + 2, (size_t)nf * 4)) return rc;
+        if (int rc = ensure_stage(c, 4 * set + 3, (size_t)nf * 4)) return rc;
+        void** st = c->stage + 4 * set;
+        LDPC_HIP(c, hipMemcpyAsync(st[0], (const char*)in + (size_t)f0 * n * in_elem, (size_t)nf * n * in_elem,
+                                   hipMemcpyHostToDevice, s));
+        if (i > 0) LDPC_HIP(c, hipStreamWaitEvent(s, c->io_decoded[set ^ 1], 0));
+        SrcArgs src{bsc ? Src::Bsc : Src::Float, (const float*)st[0], (const uint8_t*)st[0], l0, l1};
+        if (int rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)st[1], (int32_t*)st[2], (int32_t*)st[3], s))
+            return rc;
+        LDPC_HIP(c, hipEventRecord(c->io_decoded[set], s));
+        // the previous chunk's results travel while this chunk is decoded
+        if (i > 0)
+            if (int rc = copy_out(i - 1)) return rc;
+    }
+    if (int rc = copy_out(chunks - 1)) return rc;
+    LDPC_HIP(c, hipStreamSynchronize(c->io_stream[0]));
+    LDPC_HIP(c, hipStreamSynchronize(c->io_stream[1]));
     return LDPC_AMD_OK;
 }
 
