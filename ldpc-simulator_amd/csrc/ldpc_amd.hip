@@ -16,6 +16,7 @@
 
 #include "bp_kernels.hpp"
 #include "bp_lds.hpp"
+#include "bp_lds_gen.hpp"
 #include "bp_rows.hpp"
 #include "io_kernels.hpp"
 
@@ -54,6 +55,9 @@ struct ldpc_amd_ctx {
     int res_nt = 0;
     int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E] | edge_slot[E] | edge_pos[E]
     double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
+    // tables of the generic frame-resident engine: cn_order | vn_order | pos_of_var[n] | edge_pos[E]
+    int gen_nt = 0, gen_cn_steps = 0, gen_vn_steps = 0;
+    int* d_genres = nullptr;
     // timing of the last decode
     std::vector<hipEvent_t> ev;
     int timed_launches = 0;
@@ -233,6 +237,46 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt) {
     return LDPC_AMD_OK;
 }
 
+// Tables of the generic frame-resident engine: checks and variables sorted by degree (ties in index
+// order) and dealt out to the positions t + s * nt in that order, so that a wave meets one degree at
+// a time; -1 pads the last step.
+int build_generic_resident_tables(ldpc_amd_ctx* c, int nt) {
+    if (c->d_genres && c->gen_nt == nt) return LDPC_AMD_OK;
+    const int m = c->m, n = c->n;
+    const long long E = c->E;
+    const int cn_steps = (m + nt - 1) / nt, vn_steps = (n + nt - 1) / nt;
+    std::vector<int> tab((size_t)(cn_steps + vn_steps) * nt + (size_t)n + (size_t)E, -1);
+    int* cn_order = tab.data();
+    int* vn_order = cn_order + (size_t)cn_steps * nt;
+    int* pos_of_var = vn_order + (size_t)vn_steps * nt;
+    int* edge_pos = pos_of_var + n;
+    std::vector<int> idx((size_t)std::max(m, n));
+    for (int i = 0; i < m; ++i) idx[(size_t)i] = i;
+    std::stable_sort(idx.begin(), idx.begin() + m, [&](int a, int b) {
+        return c->h_row_ptr[(size_t)a + 1] - c->h_row_ptr[(size_t)a] > c->h_row_ptr[(size_t)b + 1] - c->h_row_ptr[(size_t)b];
+    });
+    for (int i = 0; i < m; ++i) cn_order[i] = idx[(size_t)i];
+    for (int j = 0; j < n; ++j) idx[(size_t)j] = j;
+    std::stable_sort(idx.begin(), idx.begin() + n, [&](int a, int b) {
+        return c->h_col_ptr[(size_t)a + 1] - c->h_col_ptr[(size_t)a] > c->h_col_ptr[(size_t)b + 1] - c->h_col_ptr[(size_t)b];
+    });
+    for (int q = 0; q < n; ++q) {
+        vn_order[q] = idx[(size_t)q];
+        pos_of_var[idx[(size_t)q]] = q;
+    }
+    for (long long e = 0; e < E; ++e) edge_pos[e] = pos_of_var[c->h_edge_col[(size_t)e]];
+    if (c->d_genres) {
+        LDPC_HIP(c, hipFree(c->d_genres));
+        c->d_genres = nullptr;
+    }
+    LDPC_HIP(c, hipMalloc((void**)&c->d_genres, tab.size() * sizeof(int)));
+    LDPC_HIP(c, hipMemcpy(c->d_genres, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->gen_nt = nt;
+    c->gen_cn_steps = cn_steps;
+    c->gen_vn_steps = vn_steps;
+    return LDPC_AMD_OK;
+}
+
 constexpr int kLdsMaxDegree = 128;  // 2 arrays x 128 rows x 256 B = 64 KiB per wave
 
 enum class Src { Float, Bsc };
@@ -291,7 +335,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         const size_t lds_bytes = ((size_t)c->E + (size_t)c->nw + 4) * sizeof(float);
         bool use = shape && n % (kLdsVpt * 64) == 0 && nt <= 512 && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll;
         if (const char* env = getenv("LDPC_AMD_ENGINE")) {
-            if (!strcmp(env, "stream")) use = false;
+            if (!strcmp(env, "stream") || !strcmp(env, "generic")) use = false;
         }
         if (use) {
             if (int rc = build_resident_tables(c, nt)) return rc;
@@ -324,6 +368,50 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             c->timed_launches = 1;
             c->timed_frames = frames;
             c->last_kernel = "bp_lds_kernel";
+            return LDPC_AMD_OK;
+        }
+    }
+    // Generic frame-resident engine: any code whose messages and LLRs fit at least twice into a CU's
+    // LDS and whose degrees the register code covers.
+    {
+        // about 8 variables per thread, whole wavefronts, at most 512 threads
+        const int nt = std::min(512, std::max(64, ((std::max(n, c->m) + 7) / 8 + 63) / 64 * 64));
+        const int nwp = ((n + nt - 1) / nt) * nt / 32;
+        const size_t lds_bytes = ((size_t)c->E + (size_t)n + (size_t)nwp + 4) * sizeof(float);
+        bool use = c->m > 0 && c->max_dc <= kLdsGenMaxDc && c->max_dv <= kLdsGenMaxDv && lds_bytes <= 80 * 1024 &&
+                   frames <= 0x7fffffffll;
+        if (const char* env = getenv("LDPC_AMD_ENGINE")) {
+            if (!strcmp(env, "stream")) use = false;
+        }
+        if (use) {
+            if (int rc = build_generic_resident_tables(c, nt)) return rc;
+            LdsGenParams q{};
+            q.m = c->m; q.n = n; q.nwp = nwp; q.E = c->E;
+            q.cn_steps = c->gen_cn_steps; q.vn_steps = c->gen_vn_steps;
+            q.row_ptr = c->d_row_ptr; q.col_ptr = c->d_col_ptr; q.col_edge = c->d_col_edge; q.edge_col = c->d_edge_col;
+            q.cn_order = c->d_genres; q.vn_order = q.cn_order + (size_t)q.cn_steps * nt;
+            q.pos_of_var = q.vn_order + (size_t)q.vn_steps * nt; q.edge_pos = q.pos_of_var + n;
+            q.llr = src.kind == Src::Float ? src.llr : nullptr;
+            q.r = src.kind == Src::Bsc ? src.r : nullptr;
+            q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
+            q.scale = (float)llr_scale(c);
+            q.frames = frames; q.max_iters = max_iters;
+            q.hard = d_hard; q.out_iters = d_iters; q.out_synd = d_synd;
+            LdsGenLaunch l;
+            l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
+                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
+            l.early = early; l.threads = nt; l.lds_bytes = lds_bytes; l.stream = s;
+            while (c->ev.size() < 2) {
+                hipEvent_t e;
+                LDPC_HIP(c, hipEventCreate(&e));
+                c->ev.push_back(e);
+            }
+            LDPC_HIP(c, hipEventRecord(c->ev[0], s));
+            LDPC_HIP(c, bp_lds_gen_launch(l, q));
+            LDPC_HIP(c, hipEventRecord(c->ev[1], s));
+            c->timed_launches = 1;
+            c->timed_frames = frames;
+            c->last_kernel = "bp_lds_gen_kernel";
             return LDPC_AMD_OK;
         }
     }
@@ -614,7 +702,7 @@ int ldpc_amd_destroy(ldpc_amd_ctx* c) {
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
         void* ptrs[] = {c->d_row_ptr, c->d_edge_col, c->d_col_ptr, c->d_col_edge, c->ws, c->d_res,
                         c->stage[0],  c->stage[1],   c->stage[2],  c->stage[3],   c->d_counters, c->d_gen,      c->stage_cw,
-                        c->stage[4],  c->stage[5],   c->stage[6],  c->stage[7]};
+                        c->stage[4],  c->stage[5],   c->stage[6],  c->stage[7],   c->d_genres};
         for (int i = 0; i < 2; ++i) {
             if (c->io_stream[i]) (void)hipStreamDestroy(c->io_stream[i]);
             if (c->io_decoded[i]) (void)hipEventDestroy(c->io_decoded[i]);

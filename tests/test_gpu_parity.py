@@ -13,9 +13,11 @@ import os
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["resident", "stream_tiles", "stream_rows"])
+@pytest.fixture(autouse=True, params=["resident", "resident_generic", "stream_tiles", "stream_rows"])
 def engine(request):
-    """Regular codes that fit in LDS run the frame-resident engine by default.  Every test also runs
+    """Codes that fit in LDS run a frame-resident engine by default: the kernels specialised for the
+    (6,3) and (8,2) regular codes, or the generic one (any degrees up to 20 / 32), which
+    LDPC_AMD_ENGINE=generic forces also where a specialised kernel exists.  Every test also runs
     with the frame-major streaming engine forced (LDPC_AMD_ENGINE=stream), once as the one-launch
     kernel that gives each wavefront its own tile (LDPC_AMD_ROWS=0) and once as row-parallel sweep
     launches (LDPC_AMD_ROWS=1, the default for small batches)."""
@@ -23,7 +25,9 @@ def engine(request):
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)
-    if request.param != "resident":
+    if request.param == "resident_generic":
+        os.environ["LDPC_AMD_ENGINE"] = "generic"
+    elif request.param != "resident":
         os.environ["LDPC_AMD_ENGINE"] = "stream"
         os.environ["LDPC_AMD_ROWS"] = "1" if request.param == "stream_rows" else "0"
     yield request.param
@@ -204,8 +208,9 @@ def test_engines_return_identical_bits(c1, c2, oracle, engine):
             os.environ.pop("LDPC_AMD_ENGINE", None)
             a = c["dec"].decode_batch(llr, L, early)
             assert c["dec"].last_decode_kernel() == "bp_lds_kernel"
-            os.environ["LDPC_AMD_ENGINE"] = "stream"
-            for rows_mode, kernel in (("0", "bp_decode_kernel"), ("1", "rows_cn_kernel")):
+            for eng, rows_mode, kernel in (("generic", "0", "bp_lds_gen_kernel"), ("stream", "0", "bp_decode_kernel"),
+                                           ("stream", "1", "rows_cn_kernel")):
+                os.environ["LDPC_AMD_ENGINE"] = eng
                 os.environ["LDPC_AMD_ROWS"] = rows_mode
                 b = c["dec"].decode_batch(llr, L, early)
                 assert c["dec"].last_decode_kernel() == kernel
@@ -216,9 +221,10 @@ def test_engines_return_identical_bits(c1, c2, oracle, engine):
             assert (a[2] > 0).any()
 
 
-def test_irregular_degrees_register_and_lds_paths(pkg, oracle):
+def test_irregular_degrees_register_and_lds_paths(pkg, oracle, engine):
     """NR-BG1-shaped code at a small lifting size: check degrees 3..19 and variable degrees
-    1..30 go through the register path (<= 16) and the LDS-staged path (> 16)."""
+    1..30 go through the register path (<= 16) and the LDS-staged path (> 16) of the streaming
+    kernels, and through the generic frame-resident kernel by default (it fits in LDS)."""
     base, (m, n, rows, cols) = pkg.codes.nr_bg1_shaped(z=8, seed=1)
     dec = pkg.Decoder(m, n, rows, cols)
     assert dec.max_dc == 19 and dec.max_dv >= 29
@@ -227,6 +233,8 @@ def test_irregular_degrees_register_and_lds_paths(pkg, oracle):
     llr = oracle.gen_awgn_llr(m, n, 3.0, seed=2, first_frame=0, frames=F)
     for early in (True, False):
         got = dec.decode_batch(llr, 15, early)
+        assert dec.last_decode_kernel() == {"resident": "bp_lds_gen_kernel", "resident_generic": "bp_lds_gen_kernel",
+                                            "stream_tiles": "bp_decode_kernel", "stream_rows": "rows_cn_kernel"}[engine]
         want = g.decode_llr_batch(llr, 15, early)
         frac, diff = _agreement(got, want)
         assert frac >= 0.995, (early, frac, diff[:10])
