@@ -6,7 +6,7 @@
 // that order to the positions p = t + s * nt (thread t, step s), so the 64 lanes of a wave at one step
 // hold nodes of (nearly) one degree and the per-degree code of cn_dispatch / vn_dispatch
 // (bp_kernels.hpp: the same fully unrolled register code as the streaming engines, hence the same
-// bits) runs with little divergence.  Positions past the last node hold -1.
+// bits) runs with little divergence.  Positions past the last node are marked empty.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,11 +23,10 @@ struct LdsGenParams {
     long long E;
     int cn_steps, vn_steps; // positions per thread
     const int* row_ptr;     // [m+1]
-    const int* col_ptr;     // [n+1]
     const int* col_edge;    // [E] CSR edge ids of a variable, ascending check
     const int* edge_col;    // [E] variable of CSR edge e
-    const int* cn_order;    // [cn_steps*nt] check at CN position p, or -1
-    const int* vn_order;    // [vn_steps*nt] variable at VN position p, or -1
+    const int2* cn_desc;    // [cn_steps*nt] check at CN position p: (first edge, degree); degree 0 pads
+    const int4* vn_desc;    // [vn_steps*nt] variable at VN position p: (j, first entry in col_edge, degree, 0); j = -1 pads
     const int* pos_of_var;  // [n]
     const int* edge_pos;    // [E] VN position of the variable of CSR edge e (its decision bit index)
     const float* llr;       // [frames][n] channel LLRs, or null
@@ -98,23 +97,18 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
     for (int it = 0; it < p.max_iters; ++it) {
         // check nodes: beta -> alpha in place (LogDecoder.java:82-95)
         for (int s = 0; s < p.cn_steps; ++s) {
-            const int i = p.cn_order[t + s * nt];
-            if (i >= 0) {
-                const int e0 = p.row_ptr[i];
-                cn_dispatch<1, RULE, false>(p.row_ptr[i + 1] - e0, msg + e0, nullptr, nullptr, 1, 1, nullptr, 0, lane);
-            }
+            const int2 cd = p.cn_desc[t + s * nt];
+            if (cd.y > 0) cn_dispatch<1, RULE, false>(cd.y, msg + cd.x, nullptr, nullptr, 1, 1, nullptr, 0, lane);
         }
         __syncthreads();
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit (:67-79, :98-105)
         const bool write_beta = EARLY || (it + 1 < p.max_iters);
         for (int s = 0; s < p.vn_steps; ++s) {
             const int pos = t + s * nt;
-            const int j = p.vn_order[pos];
+            const int4 vd = p.vn_desc[pos];
+            const int j = vd.x;
             float g[1] = {0.0f};
-            if (j >= 0) {
-                const int c0 = p.col_ptr[j];
-                vn_dispatch<1>(p.col_ptr[j + 1] - c0, msg, lam + j, p.col_edge + c0, 1, write_beta, g, nullptr, 0, lane);
-            }
+            if (j >= 0) vn_dispatch<1>(vd.z, msg, lam + j, p.col_edge + vd.y, 1, write_beta, g, nullptr, 0, lane);
             if (EARLY || it + 1 == p.max_iters) {
                 const unsigned long long mask = __ballot(j >= 0 && g[0] < 0.0f);  // "(gamma[j] < 0) ? 1 : 0", :104
                 if (lane == 0) {  // pos is a multiple of 64 here

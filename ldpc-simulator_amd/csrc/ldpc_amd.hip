@@ -55,7 +55,7 @@ struct ldpc_amd_ctx {
     int res_nt = 0;
     int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E] | edge_slot[E] | edge_pos[E]
     double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
-    // tables of the generic frame-resident engine: cn_order | vn_order | pos_of_var[n] | edge_pos[E]
+    // tables of the generic frame-resident engine: cn_desc | vn_desc | pos_of_var[n] | edge_pos[E]
     int gen_nt = 0, gen_cn_steps = 0, gen_vn_steps = 0;
     int* d_genres = nullptr;
     // timing of the last decode
@@ -245,24 +245,33 @@ int build_generic_resident_tables(ldpc_amd_ctx* c, int nt) {
     const int m = c->m, n = c->n;
     const long long E = c->E;
     const int cn_steps = (m + nt - 1) / nt, vn_steps = (n + nt - 1) / nt;
-    std::vector<int> tab((size_t)(cn_steps + vn_steps) * nt + (size_t)n + (size_t)E, -1);
-    int* cn_order = tab.data();
-    int* vn_order = cn_order + (size_t)cn_steps * nt;
-    int* pos_of_var = vn_order + (size_t)vn_steps * nt;
+    // layout: cn_desc int2[cn_steps*nt] | vn_desc int4[vn_steps*nt] | pos_of_var[n] | edge_pos[E]
+    std::vector<int> tab((size_t)2 * cn_steps * nt + (size_t)4 * vn_steps * nt + (size_t)n + (size_t)E, 0);
+    int* cn_desc = tab.data();
+    int* vn_desc = cn_desc + (size_t)2 * cn_steps * nt;
+    int* pos_of_var = vn_desc + (size_t)4 * vn_steps * nt;
     int* edge_pos = pos_of_var + n;
+    for (int q = 0; q < vn_steps * nt; ++q) vn_desc[4 * q] = -1;
     std::vector<int> idx((size_t)std::max(m, n));
     for (int i = 0; i < m; ++i) idx[(size_t)i] = i;
     std::stable_sort(idx.begin(), idx.begin() + m, [&](int a, int b) {
         return c->h_row_ptr[(size_t)a + 1] - c->h_row_ptr[(size_t)a] > c->h_row_ptr[(size_t)b + 1] - c->h_row_ptr[(size_t)b];
     });
-    for (int i = 0; i < m; ++i) cn_order[i] = idx[(size_t)i];
+    for (int q = 0; q < m; ++q) {
+        const int i = idx[(size_t)q];
+        cn_desc[2 * q] = c->h_row_ptr[(size_t)i];
+        cn_desc[2 * q + 1] = c->h_row_ptr[(size_t)i + 1] - c->h_row_ptr[(size_t)i];
+    }
     for (int j = 0; j < n; ++j) idx[(size_t)j] = j;
     std::stable_sort(idx.begin(), idx.begin() + n, [&](int a, int b) {
         return c->h_col_ptr[(size_t)a + 1] - c->h_col_ptr[(size_t)a] > c->h_col_ptr[(size_t)b + 1] - c->h_col_ptr[(size_t)b];
     });
     for (int q = 0; q < n; ++q) {
-        vn_order[q] = idx[(size_t)q];
-        pos_of_var[idx[(size_t)q]] = q;
+        const int j = idx[(size_t)q];
+        vn_desc[4 * q] = j;
+        vn_desc[4 * q + 1] = c->h_col_ptr[(size_t)j];
+        vn_desc[4 * q + 2] = c->h_col_ptr[(size_t)j + 1] - c->h_col_ptr[(size_t)j];
+        pos_of_var[j] = q;
     }
     for (long long e = 0; e < E; ++e) edge_pos[e] = pos_of_var[c->h_edge_col[(size_t)e]];
     if (c->d_genres) {
@@ -388,9 +397,11 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             LdsGenParams q{};
             q.m = c->m; q.n = n; q.nwp = nwp; q.E = c->E;
             q.cn_steps = c->gen_cn_steps; q.vn_steps = c->gen_vn_steps;
-            q.row_ptr = c->d_row_ptr; q.col_ptr = c->d_col_ptr; q.col_edge = c->d_col_edge; q.edge_col = c->d_edge_col;
-            q.cn_order = c->d_genres; q.vn_order = q.cn_order + (size_t)q.cn_steps * nt;
-            q.pos_of_var = q.vn_order + (size_t)q.vn_steps * nt; q.edge_pos = q.pos_of_var + n;
+            q.row_ptr = c->d_row_ptr; q.col_edge = c->d_col_edge; q.edge_col = c->d_edge_col;
+            q.cn_desc = reinterpret_cast<const int2*>(c->d_genres);
+            q.vn_desc = reinterpret_cast<const int4*>(c->d_genres + (size_t)2 * q.cn_steps * nt);
+            q.pos_of_var = c->d_genres + (size_t)2 * q.cn_steps * nt + (size_t)4 * q.vn_steps * nt;
+            q.edge_pos = q.pos_of_var + n;
             q.llr = src.kind == Src::Float ? src.llr : nullptr;
             q.r = src.kind == Src::Bsc ? src.r : nullptr;
             q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
