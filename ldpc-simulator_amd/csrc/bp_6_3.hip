@@ -3,4 +3,6 @@
 
 namespace ldpc {
 void bp_launch_6_3(const BpLaunch& l, const BpParams& p) { bp_launch_impl<6, 3>(l, p); }
+unsigned bp_6_3_params_bytes() { return (unsigned)sizeof(BpParams); }
+
 }  // namespace ldpc

@@ -3,4 +3,6 @@
 
 namespace ldpc {
 void bp_launch_generic(const BpLaunch& l, const BpParams& p) { bp_launch_impl<0, 0>(l, p); }
+unsigned bp_generic_params_bytes() { return (unsigned)sizeof(BpParams); }
+
 }  // namespace ldpc

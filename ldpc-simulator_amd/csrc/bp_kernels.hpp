@@ -40,6 +40,13 @@ constexpr int kRegDegVn = LDPC_REG_DEG_VN;
 constexpr int kRegDegFpl1 = 16;  // the one-launch kernels' limit for both
 constexpr int kRegDegFpl4 = 8;   // ... and with 2 or 4 frames per lane
 
+// Host code and kernels live in different objects.  Every translation unit that holds kernels also
+// exports the size of the parameter struct it was compiled with; ldpc_amd_create compares those
+// with its own, so a stale object cannot run with pointers read from the wrong offsets.
+unsigned bp_generic_params_bytes();
+unsigned bp_6_3_params_bytes();
+unsigned bp_8_2_params_bytes();
+
 struct BpParams {
     int m, n, nw;            // checks, variables, 32-bit decision words per frame
     const int* row_ptr;      // [m+1] CSR: edges of check i, ascending column

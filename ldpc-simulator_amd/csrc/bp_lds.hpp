@@ -255,6 +255,8 @@ inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
 }
 
 hipError_t bp_lds_launch_6_3(const LdsLaunch& l, const LdsParams& p);
+unsigned bp_lds_6_3_params_bytes();  // see bp_kernels.hpp
+unsigned bp_lds_8_2_params_bytes();
 hipError_t bp_lds_launch_8_2(const LdsLaunch& l, const LdsParams& p);
 
 }  // namespace ldpc

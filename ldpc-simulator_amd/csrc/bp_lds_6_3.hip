@@ -4,4 +4,6 @@
 
 namespace ldpc {
 hipError_t bp_lds_launch_6_3(const LdsLaunch& l, const LdsParams& p) { return bp_lds_launch_impl<6, 3, 4>(l, p); }
+unsigned bp_lds_6_3_params_bytes() { return (unsigned)sizeof(LdsParams); }
+
 }  // namespace ldpc

@@ -29,4 +29,6 @@ hipError_t bp_lds_gen_launch(const LdsGenLaunch& l, const LdsGenParams& p) {
     return hipGetLastError();
 }
 
+unsigned bp_lds_gen_params_bytes() { return (unsigned)sizeof(LdsGenParams); }
+
 }  // namespace ldpc

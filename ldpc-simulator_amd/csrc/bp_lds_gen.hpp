@@ -150,5 +150,6 @@ struct LdsGenLaunch {
 };
 
 hipError_t bp_lds_gen_launch(const LdsGenLaunch& l, const LdsGenParams& p);
+unsigned bp_lds_gen_params_bytes();  // see bp_kernels.hpp
 
 }  // namespace ldpc

@@ -55,4 +55,6 @@ hipError_t bp_rows_run(const RowsLaunch& l, RowsParams p) {
     return run_fpl<0, 0>(l, p);
 }
 
+unsigned bp_rows_params_bytes() { return (unsigned)sizeof(RowsParams); }
+
 }  // namespace ldpc

@@ -199,5 +199,6 @@ struct RowsLaunch {
 
 // All launches of one decode of the tiles in p.b (state arrays zeroed by the caller).
 hipError_t bp_rows_run(const RowsLaunch& l, RowsParams p);
+unsigned bp_rows_params_bytes();  // see bp_kernels.hpp
 
 }  // namespace ldpc

@@ -671,6 +671,12 @@ int ldpc_amd_create(int32_t m, int32_t n, int64_t nnz, const int32_t* row_idx, c
     *out = nullptr;
     if (m < 0 || n <= 0 || nnz < 0 || (nnz > 0 && (!row_idx || !col_idx)))
         return fail(nullptr, LDPC_AMD_EINVAL, "create: bad matrix shape or null index arrays");
+    // every kernel object must have been compiled with the parameter structs this file uses
+    if (bp_generic_params_bytes() != sizeof(BpParams) || bp_6_3_params_bytes() != sizeof(BpParams) ||
+        bp_8_2_params_bytes() != sizeof(BpParams) || bp_lds_6_3_params_bytes() != sizeof(LdsParams) ||
+        bp_lds_8_2_params_bytes() != sizeof(LdsParams) || bp_lds_gen_params_bytes() != sizeof(LdsGenParams) ||
+        bp_rows_params_bytes() != sizeof(RowsParams))
+        return fail(nullptr, LDPC_AMD_EHIP, "create: the library was linked from objects built against different headers");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, LDPC_AMD_ENODEV, "create: no HIP device (this library has no CPU path)");
