@@ -3,10 +3,13 @@
 // for all iterations (see bp_lds.hpp for the specialised regular-code version of the same idea).
 //
 // Degrees are per node here.  The host sorts checks and variables by degree and deals them out in
-// that order to the positions p = t + s * nt (thread t, step s), so the 64 lanes of a wave at one step
-// hold nodes of (nearly) one degree and the per-degree code of cn_dispatch / vn_dispatch
-// (bp_kernels.hpp: the same fully unrolled register code as the streaming engines, hence the same
-// bits) runs with little divergence.  Positions past the last node are marked empty.
+// that order, two neighbours of the sorted list at a time, to the work items t + u * nt (thread t,
+// step u): the 64 lanes of a wave at one step hold nodes of (nearly) one degree, so the per-degree
+// code runs with little divergence, and the two nodes of an item nearly always have the same degree,
+// in which case they share packed registers (cn_complement<v2f, D> / vn_compute_v<v2f, D>: the same
+// operations as the scalar code of the streaming engines, hence the same bits).  Items whose two
+// degrees differ, and the other check-node rules, go through cn_dispatch / vn_dispatch one node at a
+// time.  Slots past the last node are marked empty.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,16 +20,18 @@ namespace ldpc {
 
 // limits of the register code this engine is compiled with (bp_lds_gen.hip); codes above them stream
 constexpr int kLdsGenMaxDc = 20, kLdsGenMaxDv = 32;
+// degrees up to which two nodes share packed registers (beyond that the register file does not hold a pair)
+constexpr int kLdsGenPairDc = 10, kLdsGenPairDv = 8;
 
 struct LdsGenParams {
-    int m, n, nwp;          // nwp: words of decisions = vn_steps * nt / 32
+    int m, n, nwp;          // nwp: words of decisions = 2 * vn_steps * nt / 32
     long long E;
-    int cn_steps, vn_steps; // positions per thread
+    int cn_steps, vn_steps; // work items (pairs of nodes) per thread
     const int* row_ptr;     // [m+1]
     const int* col_edge;    // [E] CSR edge ids of a variable, ascending check
     const int* edge_col;    // [E] variable of CSR edge e
-    const int2* cn_desc;    // [cn_steps*nt] check at CN position p: (first edge, degree); degree 0 pads
-    const int4* vn_desc;    // [vn_steps*nt] variable at VN position p: (j, first entry in col_edge, degree, 0); j = -1 pads
+    const int4* cn_desc;    // [cn_steps*nt] two checks: (first edge a, degree a, first edge b, degree b); degree 0 = none
+    const int4* vn_desc;    // [vn_steps*nt][2] two variables: (j, first entry in col_edge, degree, 0) each; j = -1 = none
     const int* pos_of_var;  // [n]
     const int* edge_pos;    // [E] VN position of the variable of CSR edge e (its decision bit index)
     const float* llr;       // [frames][n] channel LLRs, or null
@@ -64,6 +69,52 @@ __device__ __forceinline__ int lds_gen_syndrome(const LdsGenParams& p, const uin
     return total;
 }
 
+// two checks of degree D in packed registers
+template <int D>
+__device__ __forceinline__ void gen_cn_pair(float* msg, int ea, int eb) {
+    v2f x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = v2f{msg[ea + k], msg[eb + k]};
+    cn_complement<v2f, D>(x);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        msg[ea + k] = x[k].x;
+        msg[eb + k] = x[k].y;
+    }
+}
+
+// two variables of degree D in packed registers; returns the two posteriors
+template <int D>
+__device__ __forceinline__ v2f gen_vn_pair(float* msg, const float* lam, const int* col_edge, int4 a, int4 b, bool write_beta) {
+    const v2f l = v2f{lam[a.x], lam[b.x]};
+    if constexpr (D == 0) {
+        return l;
+    } else {
+        int ia[D], ib[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            ia[k] = col_edge[a.y + k];
+            ib[k] = col_edge[b.y + k];
+        }
+        v2f x[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = v2f{msg[ia[k]], msg[ib[k]]};
+        v2f g;
+        vn_compute_v<v2f, D>(x, l, g);
+        if (write_beta) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                msg[ia[k]] = x[k].x;
+                msg[ib[k]] = x[k].y;
+            }
+        }
+        return g;
+    }
+}
+
+#define LDPC_GEN_CN(D) case D: gen_cn_pair<D>(msg, cd.x, cd.z); break;
+#define LDPC_GEN_VN(D) case D: g = gen_vn_pair<D>(msg, lam, p.col_edge, va, vb, write_beta); break;
+
 template <int RULE, bool EARLY>
 __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
     extern __shared__ __align__(16) float smem_gen[];
@@ -97,23 +148,53 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
     for (int it = 0; it < p.max_iters; ++it) {
         // check nodes: beta -> alpha in place (LogDecoder.java:82-95)
         for (int s = 0; s < p.cn_steps; ++s) {
-            const int2 cd = p.cn_desc[t + s * nt];
-            if (cd.y > 0) cn_dispatch<1, RULE, false>(cd.y, msg + cd.x, nullptr, nullptr, 1, 1, nullptr, 0, lane);
+            const int4 cd = p.cn_desc[t + s * nt];
+            if (RULE == kCnComplement && cd.y == cd.w && cd.y <= kLdsGenPairDc) {
+                switch (cd.y) {
+                    case 0: break;
+                    LDPC_GEN_CN(1) LDPC_GEN_CN(2) LDPC_GEN_CN(3) LDPC_GEN_CN(4) LDPC_GEN_CN(5)
+                    LDPC_GEN_CN(6) LDPC_GEN_CN(7) LDPC_GEN_CN(8) LDPC_GEN_CN(9) LDPC_GEN_CN(10)
+                    default: break;
+                }
+            } else {
+                if (cd.y > 0) cn_dispatch<1, RULE, false>(cd.y, msg + cd.x, nullptr, nullptr, 1, 1, nullptr, 0, lane);
+                if (cd.w > 0) cn_dispatch<1, RULE, false>(cd.w, msg + cd.z, nullptr, nullptr, 1, 1, nullptr, 0, lane);
+            }
         }
         __syncthreads();
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit (:67-79, :98-105)
         const bool write_beta = EARLY || (it + 1 < p.max_iters);
         for (int s = 0; s < p.vn_steps; ++s) {
-            const int pos = t + s * nt;
-            const int4 vd = p.vn_desc[pos];
-            const int j = vd.x;
-            float g[1] = {0.0f};
-            if (j >= 0) vn_dispatch<1>(vd.z, msg, lam + j, p.col_edge + vd.y, 1, write_beta, g, nullptr, 0, lane);
+            const int item = t + s * nt;
+            const int4 va = p.vn_desc[2 * item], vb = p.vn_desc[2 * item + 1];
+            v2f g = v2f{0.0f, 0.0f};
+            if (va.x >= 0 && vb.x >= 0 && va.z == vb.z && va.z <= kLdsGenPairDv) {
+                switch (va.z) {
+                    LDPC_GEN_VN(0) LDPC_GEN_VN(1) LDPC_GEN_VN(2) LDPC_GEN_VN(3) LDPC_GEN_VN(4) LDPC_GEN_VN(5)
+                    LDPC_GEN_VN(6) LDPC_GEN_VN(7) LDPC_GEN_VN(8)
+                    default: break;
+                }
+            } else {
+                float g1[1] = {0.0f};
+                if (va.x >= 0) {
+                    vn_dispatch<1>(va.z, msg, lam + va.x, p.col_edge + va.y, 1, write_beta, g1, nullptr, 0, lane);
+                    g.x = g1[0];
+                }
+                if (vb.x >= 0) {
+                    vn_dispatch<1>(vb.z, msg, lam + vb.x, p.col_edge + vb.y, 1, write_beta, g1, nullptr, 0, lane);
+                    g.y = g1[0];
+                }
+            }
             if (EARLY || it + 1 == p.max_iters) {
-                const unsigned long long mask = __ballot(j >= 0 && g[0] < 0.0f);  // "(gamma[j] < 0) ? 1 : 0", :104
-                if (lane == 0) {  // pos is a multiple of 64 here
-                    bits[pos >> 5] = (uint32_t)mask;
-                    bits[(pos >> 5) + 1] = (uint32_t)(mask >> 32);
+                // "(gamma[j] < 0) ? 1 : 0", :104; decision position of the item's first variable:
+                // 128 * (item / 64) + item % 64, of its second: 64 more
+                const unsigned long long ma = __ballot(va.x >= 0 && g.x < 0.0f), mb = __ballot(vb.x >= 0 && g.y < 0.0f);
+                if (lane == 0) {  // item is a multiple of 64 here
+                    uint32_t* w = bits + 4 * (item >> 6);
+                    w[0] = (uint32_t)ma;
+                    w[1] = (uint32_t)(ma >> 32);
+                    w[2] = (uint32_t)mb;
+                    w[3] = (uint32_t)(mb >> 32);
                 }
             }
         }
@@ -138,6 +219,9 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
         if (p.out_synd) p.out_synd[frame] = synd;
     }
 }
+
+#undef LDPC_GEN_CN
+#undef LDPC_GEN_VN
 
 #endif  // LDPC_LDS_GEN_KERNELS
 

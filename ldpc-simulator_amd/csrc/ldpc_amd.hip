@@ -238,26 +238,29 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt) {
 }
 
 // Tables of the generic frame-resident engine: checks and variables sorted by degree (ties in index
-// order) and dealt out to the positions t + s * nt in that order, so that a wave meets one degree at
-// a time; -1 pads the last step.
+// order); neighbours 2q, 2q+1 of the sorted list form work item q, and the items are dealt out to the
+// slots t + u * nt in that order, so that a wave meets one degree at a time and the two nodes of an
+// item nearly always share a degree.  The decision bit of the variable that is node h of item q sits at
+// position 128 * (q / 64) + 64 * h + q % 64 (one 64-bit ballot per half).
 int build_generic_resident_tables(ldpc_amd_ctx* c, int nt) {
     if (c->d_genres && c->gen_nt == nt) return LDPC_AMD_OK;
     const int m = c->m, n = c->n;
     const long long E = c->E;
-    const int cn_steps = (m + nt - 1) / nt, vn_steps = (n + nt - 1) / nt;
-    // layout: cn_desc int2[cn_steps*nt] | vn_desc int4[vn_steps*nt] | pos_of_var[n] | edge_pos[E]
-    std::vector<int> tab((size_t)2 * cn_steps * nt + (size_t)4 * vn_steps * nt + (size_t)n + (size_t)E, 0);
+    const int cn_items = (m + 1) / 2, vn_items = (n + 1) / 2;
+    const int cn_steps = (cn_items + nt - 1) / nt, vn_steps = (vn_items + nt - 1) / nt;
+    // layout: cn_desc int4[cn_steps*nt] | vn_desc int4[vn_steps*nt][2] | pos_of_var[n] | edge_pos[E]
+    std::vector<int> tab((size_t)4 * cn_steps * nt + (size_t)8 * vn_steps * nt + (size_t)n + (size_t)E, 0);
     int* cn_desc = tab.data();
-    int* vn_desc = cn_desc + (size_t)2 * cn_steps * nt;
-    int* pos_of_var = vn_desc + (size_t)4 * vn_steps * nt;
+    int* vn_desc = cn_desc + (size_t)4 * cn_steps * nt;
+    int* pos_of_var = vn_desc + (size_t)8 * vn_steps * nt;
     int* edge_pos = pos_of_var + n;
-    for (int q = 0; q < vn_steps * nt; ++q) vn_desc[4 * q] = -1;
+    for (int q = 0; q < 2 * vn_steps * nt; ++q) vn_desc[4 * q] = -1;
     std::vector<int> idx((size_t)std::max(m, n));
     for (int i = 0; i < m; ++i) idx[(size_t)i] = i;
     std::stable_sort(idx.begin(), idx.begin() + m, [&](int a, int b) {
         return c->h_row_ptr[(size_t)a + 1] - c->h_row_ptr[(size_t)a] > c->h_row_ptr[(size_t)b + 1] - c->h_row_ptr[(size_t)b];
     });
-    for (int q = 0; q < m; ++q) {
+    for (int q = 0; q < m; ++q) {  // node q & 1 of item q >> 1
         const int i = idx[(size_t)q];
         cn_desc[2 * q] = c->h_row_ptr[(size_t)i];
         cn_desc[2 * q + 1] = c->h_row_ptr[(size_t)i + 1] - c->h_row_ptr[(size_t)i];
@@ -271,7 +274,8 @@ int build_generic_resident_tables(ldpc_amd_ctx* c, int nt) {
         vn_desc[4 * q] = j;
         vn_desc[4 * q + 1] = c->h_col_ptr[(size_t)j];
         vn_desc[4 * q + 2] = c->h_col_ptr[(size_t)j + 1] - c->h_col_ptr[(size_t)j];
-        pos_of_var[j] = q;
+        const int item = q >> 1, half = q & 1;
+        pos_of_var[j] = 128 * (item / 64) + 64 * half + item % 64;
     }
     for (long long e = 0; e < E; ++e) edge_pos[e] = pos_of_var[c->h_edge_col[(size_t)e]];
     if (c->d_genres) {
@@ -385,7 +389,8 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     {
         // about 8 variables per thread, whole wavefronts, at most 512 threads
         const int nt = std::min(512, std::max(64, ((std::max(n, c->m) + 7) / 8 + 63) / 64 * 64));
-        const int nwp = ((n + nt - 1) / nt) * nt / 32;
+        const int vn_steps = ((n + 1) / 2 + nt - 1) / nt;
+        const int nwp = 2 * vn_steps * nt / 32;
         const size_t lds_bytes = ((size_t)c->E + (size_t)n + (size_t)nwp + 4) * sizeof(float);
         // up to the whole LDS of a CU: even at one workgroup per CU this engine measured 1.5x (fixed
         // iterations) to 3x (early exit) the streaming engine
@@ -402,9 +407,9 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             q.m = c->m; q.n = n; q.nwp = nwp; q.E = c->E;
             q.cn_steps = c->gen_cn_steps; q.vn_steps = c->gen_vn_steps;
             q.row_ptr = c->d_row_ptr; q.col_edge = c->d_col_edge; q.edge_col = c->d_edge_col;
-            q.cn_desc = reinterpret_cast<const int2*>(c->d_genres);
-            q.vn_desc = reinterpret_cast<const int4*>(c->d_genres + (size_t)2 * q.cn_steps * nt);
-            q.pos_of_var = c->d_genres + (size_t)2 * q.cn_steps * nt + (size_t)4 * q.vn_steps * nt;
+            q.cn_desc = reinterpret_cast<const int4*>(c->d_genres);
+            q.vn_desc = reinterpret_cast<const int4*>(c->d_genres + (size_t)4 * q.cn_steps * nt);
+            q.pos_of_var = c->d_genres + (size_t)4 * q.cn_steps * nt + (size_t)8 * q.vn_steps * nt;
             q.edge_pos = q.pos_of_var + n;
             q.llr = src.kind == Src::Float ? src.llr : nullptr;
             q.r = src.kind == Src::Bsc ? src.r : nullptr;
