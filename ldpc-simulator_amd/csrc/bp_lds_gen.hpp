@@ -1,6 +1,12 @@
 // Frame-resident flooding belief propagation for any code whose messages fit in LDS: one workgroup
-// decodes one frame, msg[E] (CSR edge order), the channel LLRs and the packed decisions stay in LDS
-// for all iterations (see bp_lds.hpp for the specialised regular-code version of the same idea).
+// decodes one frame; its messages, the channel LLRs and the packed decisions stay in LDS for all
+// iterations (see bp_lds.hpp for the specialised regular-code version of the same idea).
+//
+// Message slots: the 128 checks that one wave handles in one step (64 lanes x 2 checks) form a block
+// laid out as [position in the row][check 0/1 of the lane][lane], so every check-node access of a
+// wave is 64 consecutive words (no bank conflict, whatever the degree); a block is as deep as its
+// largest degree.  The variable side reaches its messages through a slot table in place of CSR edge
+// ids.
 //
 // Degrees are per node here.  The host sorts checks and variables by degree and deals them out in
 // that order, two neighbours of the sorted list at a time, to the work items t + u * nt (thread t,
@@ -22,16 +28,20 @@ namespace ldpc {
 constexpr int kLdsGenMaxDc = 20, kLdsGenMaxDv = 32;
 // degrees up to which two nodes share packed registers (beyond that the register file does not hold a pair)
 constexpr int kLdsGenPairDc = 10, kLdsGenPairDv = 8;
+constexpr int kGenRowStride = 128;  // words between consecutive positions of a check's row (2 checks x 64 lanes)
 
 struct LdsGenParams {
     int m, n, nwp;          // nwp: words of decisions = 2 * vn_steps * nt / 32
     long long E;
+    int slots;              // message words in LDS (E plus the padding of blocks with mixed degrees)
     int cn_steps, vn_steps; // work items (pairs of nodes) per thread
     const int* row_ptr;     // [m+1]
-    const int* col_edge;    // [E] CSR edge ids of a variable, ascending check
+    const int* col_slot;    // [E] message slots of a variable's edges, ascending check (CSC order)
     const int* edge_col;    // [E] variable of CSR edge e
-    const int4* cn_desc;    // [cn_steps*nt] two checks: (first edge a, degree a, first edge b, degree b); degree 0 = none
-    const int4* vn_desc;    // [vn_steps*nt][2] two variables: (j, first entry in col_edge, degree, 0) each; j = -1 = none
+    const int* edge_slot;   // [E] message slot of CSR edge e
+    const int4* cn_desc;    // [cn_steps*nt] two checks: (first slot a, degree a, first slot b, degree b); degree 0 = none;
+                            // position k of a row is kGenRowStride words after its first slot
+    const int4* vn_desc;    // [vn_steps*nt][2] two variables: (j, first entry in col_slot, degree, 0) each; j = -1 = none
     const int* pos_of_var;  // [n]
     const int* edge_pos;    // [E] VN position of the variable of CSR edge e (its decision bit index)
     const float* llr;       // [frames][n] channel LLRs, or null
@@ -74,18 +84,18 @@ template <int D>
 __device__ __forceinline__ void gen_cn_pair(float* msg, int ea, int eb) {
     v2f x[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = v2f{msg[ea + k], msg[eb + k]};
+    for (int k = 0; k < D; ++k) x[k] = v2f{msg[ea + k * kGenRowStride], msg[eb + k * kGenRowStride]};
     cn_complement<v2f, D>(x);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        msg[ea + k] = x[k].x;
-        msg[eb + k] = x[k].y;
+        msg[ea + k * kGenRowStride] = x[k].x;
+        msg[eb + k * kGenRowStride] = x[k].y;
     }
 }
 
 // two variables of degree D in packed registers; returns the two posteriors
 template <int D>
-__device__ __forceinline__ v2f gen_vn_pair(float* msg, const float* lam, const int* col_edge, int4 a, int4 b, bool write_beta) {
+__device__ __forceinline__ v2f gen_vn_pair(float* msg, const float* lam, const int* col_slot, int4 a, int4 b, bool write_beta) {
     const v2f l = v2f{lam[a.x], lam[b.x]};
     if constexpr (D == 0) {
         return l;
@@ -93,8 +103,8 @@ __device__ __forceinline__ v2f gen_vn_pair(float* msg, const float* lam, const i
         int ia[D], ib[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            ia[k] = col_edge[a.y + k];
-            ib[k] = col_edge[b.y + k];
+            ia[k] = col_slot[a.y + k];
+            ib[k] = col_slot[b.y + k];
         }
         v2f x[D];
 #pragma unroll
@@ -113,13 +123,13 @@ __device__ __forceinline__ v2f gen_vn_pair(float* msg, const float* lam, const i
 }
 
 #define LDPC_GEN_CN(D) case D: gen_cn_pair<D>(msg, cd.x, cd.z); break;
-#define LDPC_GEN_VN(D) case D: g = gen_vn_pair<D>(msg, lam, p.col_edge, va, vb, write_beta); break;
+#define LDPC_GEN_VN(D) case D: g = gen_vn_pair<D>(msg, lam, p.col_slot, va, vb, write_beta); break;
 
 template <int RULE, bool EARLY>
 __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
     extern __shared__ __align__(16) float smem_gen[];
-    float* msg = smem_gen;                                      // [E]
-    float* lam = smem_gen + p.E;                                // [n], by variable
+    float* msg = smem_gen;                                      // [slots]
+    float* lam = smem_gen + p.slots;                            // [n], by variable
     uint32_t* bits = reinterpret_cast<uint32_t*>(lam + p.n);    // [nwp], by VN position
     int* red = reinterpret_cast<int*>(bits + p.nwp);            // syndrome accumulator
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63;
@@ -141,7 +151,7 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
     for (int w = t; w < p.nwp; w += nt) bits[w] = 0u;
     if (t == 0) *red = 0;
     __syncthreads();
-    for (int e = t; e < (int)p.E; e += nt) msg[e] = lam[p.edge_col[e]] + 0.0f;
+    for (int e = t; e < (int)p.E; e += nt) msg[p.edge_slot[e]] = lam[p.edge_col[e]] + 0.0f;
     __syncthreads();
 
     int iters = p.max_iters, synd = 0;
@@ -157,8 +167,8 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
                     default: break;
                 }
             } else {
-                if (cd.y > 0) cn_dispatch<1, RULE, false>(cd.y, msg + cd.x, nullptr, nullptr, 1, 1, nullptr, 0, lane);
-                if (cd.w > 0) cn_dispatch<1, RULE, false>(cd.w, msg + cd.z, nullptr, nullptr, 1, 1, nullptr, 0, lane);
+                if (cd.y > 0) cn_dispatch<1, RULE, false>(cd.y, msg + cd.x, nullptr, nullptr, kGenRowStride, 1, nullptr, 0, lane);
+                if (cd.w > 0) cn_dispatch<1, RULE, false>(cd.w, msg + cd.z, nullptr, nullptr, kGenRowStride, 1, nullptr, 0, lane);
             }
         }
         __syncthreads();
@@ -177,11 +187,11 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
             } else {
                 float g1[1] = {0.0f};
                 if (va.x >= 0) {
-                    vn_dispatch<1>(va.z, msg, lam + va.x, p.col_edge + va.y, 1, write_beta, g1, nullptr, 0, lane);
+                    vn_dispatch<1>(va.z, msg, lam + va.x, p.col_slot + va.y, 1, write_beta, g1, nullptr, 0, lane);
                     g.x = g1[0];
                 }
                 if (vb.x >= 0) {
-                    vn_dispatch<1>(vb.z, msg, lam + vb.x, p.col_edge + vb.y, 1, write_beta, g1, nullptr, 0, lane);
+                    vn_dispatch<1>(vb.z, msg, lam + vb.x, p.col_slot + vb.y, 1, write_beta, g1, nullptr, 0, lane);
                     g.y = g1[0];
                 }
             }

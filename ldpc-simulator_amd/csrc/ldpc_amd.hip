@@ -55,8 +55,8 @@ struct ldpc_amd_ctx {
     int res_nt = 0;
     int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E] | edge_slot[E] | edge_pos[E]
     double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
-    // tables of the generic frame-resident engine: cn_desc | vn_desc | pos_of_var[n] | edge_pos[E]
-    int gen_nt = 0, gen_cn_steps = 0, gen_vn_steps = 0;
+    // tables of the generic frame-resident engine: cn_desc | vn_desc | pos_of_var[n] | edge_pos[E] | edge_slot[E] | col_slot[E]
+    int gen_nt = 0, gen_cn_steps = 0, gen_vn_steps = 0, gen_slots = 0;
     int* d_genres = nullptr;
     // timing of the last decode
     std::vector<hipEvent_t> ev;
@@ -248,22 +248,36 @@ int build_generic_resident_tables(ldpc_amd_ctx* c, int nt) {
     const long long E = c->E;
     const int cn_items = (m + 1) / 2, vn_items = (n + 1) / 2;
     const int cn_steps = (cn_items + nt - 1) / nt, vn_steps = (vn_items + nt - 1) / nt;
-    // layout: cn_desc int4[cn_steps*nt] | vn_desc int4[vn_steps*nt][2] | pos_of_var[n] | edge_pos[E]
-    std::vector<int> tab((size_t)4 * cn_steps * nt + (size_t)8 * vn_steps * nt + (size_t)n + (size_t)E, 0);
+    // layout: cn_desc int4[cn_steps*nt] | vn_desc int4[vn_steps*nt][2] | pos_of_var[n] | edge_pos[E] | edge_slot[E] | col_slot[E]
+    std::vector<int> tab((size_t)4 * cn_steps * nt + (size_t)8 * vn_steps * nt + (size_t)n + (size_t)3 * E, 0);
     int* cn_desc = tab.data();
     int* vn_desc = cn_desc + (size_t)4 * cn_steps * nt;
     int* pos_of_var = vn_desc + (size_t)8 * vn_steps * nt;
     int* edge_pos = pos_of_var + n;
+    int* edge_slot = edge_pos + E;
+    int* col_slot = edge_slot + E;
     for (int q = 0; q < 2 * vn_steps * nt; ++q) vn_desc[4 * q] = -1;
     std::vector<int> idx((size_t)std::max(m, n));
     for (int i = 0; i < m; ++i) idx[(size_t)i] = i;
     std::stable_sort(idx.begin(), idx.begin() + m, [&](int a, int b) {
         return c->h_row_ptr[(size_t)a + 1] - c->h_row_ptr[(size_t)a] > c->h_row_ptr[(size_t)b + 1] - c->h_row_ptr[(size_t)b];
     });
-    for (int q = 0; q < m; ++q) {  // node q & 1 of item q >> 1
-        const int i = idx[(size_t)q];
-        cn_desc[2 * q] = c->h_row_ptr[(size_t)i];
-        cn_desc[2 * q + 1] = c->h_row_ptr[(size_t)i + 1] - c->h_row_ptr[(size_t)i];
+    // Message slots: block (step u, wave w) holds the 128 checks of that wave's lanes in that step as
+    // [position in the row][check 0/1 of the lane][lane]; sorted descending, the first check of a block
+    // has its largest degree, which is the block's depth.
+    int slots = 0;
+    for (int item0 = 0; item0 < cn_items; item0 += 64) {  // items t = 64 w .. 64 w + 63 of step u, in order
+        const int first = idx[(size_t)(2 * item0)];
+        const int depth = c->h_row_ptr[(size_t)first + 1] - c->h_row_ptr[(size_t)first];
+        for (int q = 2 * item0; q < std::min(m, 2 * (item0 + 64)); ++q) {  // node q & 1 of item q >> 1
+            const int i = idx[(size_t)q], lane = (q >> 1) - item0, h = q & 1;
+            const int e0 = c->h_row_ptr[(size_t)i], d = c->h_row_ptr[(size_t)i + 1] - e0;
+            const int s0 = slots + h * 64 + lane;
+            cn_desc[2 * q] = s0;
+            cn_desc[2 * q + 1] = d;
+            for (int k = 0; k < d; ++k) edge_slot[e0 + k] = s0 + k * kGenRowStride;
+        }
+        slots += depth * kGenRowStride;
     }
     for (int j = 0; j < n; ++j) idx[(size_t)j] = j;
     std::stable_sort(idx.begin(), idx.begin() + n, [&](int a, int b) {
@@ -278,6 +292,7 @@ int build_generic_resident_tables(ldpc_amd_ctx* c, int nt) {
         pos_of_var[j] = 128 * (item / 64) + 64 * half + item % 64;
     }
     for (long long e = 0; e < E; ++e) edge_pos[e] = pos_of_var[c->h_edge_col[(size_t)e]];
+    for (long long t = 0; t < E; ++t) col_slot[t] = edge_slot[c->h_col_edge[(size_t)t]];
     if (c->d_genres) {
         LDPC_HIP(c, hipFree(c->d_genres));
         c->d_genres = nullptr;
@@ -287,6 +302,7 @@ int build_generic_resident_tables(ldpc_amd_ctx* c, int nt) {
     c->gen_nt = nt;
     c->gen_cn_steps = cn_steps;
     c->gen_vn_steps = vn_steps;
+    c->gen_slots = slots;
     return LDPC_AMD_OK;
 }
 
@@ -389,28 +405,34 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     {
         // about 8 variables per thread, whole wavefronts, at most 512 threads
         const int nt = std::min(512, std::max(64, ((std::max(n, c->m) + 7) / 8 + 63) / 64 * 64));
-        const int vn_steps = ((n + 1) / 2 + nt - 1) / nt;
-        const int nwp = 2 * vn_steps * nt / 32;
-        const size_t lds_bytes = ((size_t)c->E + (size_t)n + (size_t)nwp + 4) * sizeof(float);
-        // up to the whole LDS of a CU: even at one workgroup per CU this engine measured 1.5x (fixed
-        // iterations) to 3x (early exit) the streaming engine
-        size_t lds_limit = 160 * 1024;
-        if (const char* env = getenv("LDPC_AMD_GENERIC_LDS_KB")) lds_limit = (size_t)atoi(env) * 1024;  // experiments
-        bool use = c->m > 0 && c->max_dc <= kLdsGenMaxDc && c->max_dv <= kLdsGenMaxDv && lds_bytes <= lds_limit &&
-                   frames <= 0x7fffffffll;
+        bool use = c->m > 0 && c->max_dc <= kLdsGenMaxDc && c->max_dv <= kLdsGenMaxDv && frames <= 0x7fffffffll &&
+                   (size_t)c->E * sizeof(float) <= 160 * 1024;
         if (const char* env = getenv("LDPC_AMD_ENGINE")) {
             if (!strcmp(env, "stream")) use = false;
         }
+        size_t lds_bytes = 0;
+        int nwp = 0;
         if (use) {
-            if (int rc = build_generic_resident_tables(c, nt)) return rc;
+            if (int rc = build_generic_resident_tables(c, nt)) return rc;  // also gives the padded slot count
+            nwp = 2 * c->gen_vn_steps * nt / 32;
+            lds_bytes = ((size_t)c->gen_slots + (size_t)n + (size_t)nwp + 4) * sizeof(float);
+            // up to the whole LDS of a CU: even at one workgroup per CU this engine measured 1.5x (fixed
+            // iterations) to 3x (early exit) the streaming engine
+            size_t lds_limit = 160 * 1024;
+            if (const char* env = getenv("LDPC_AMD_GENERIC_LDS_KB")) lds_limit = (size_t)atoi(env) * 1024;  // experiments
+            use = lds_bytes <= lds_limit;
+        }
+        if (use) {
             LdsGenParams q{};
-            q.m = c->m; q.n = n; q.nwp = nwp; q.E = c->E;
+            q.m = c->m; q.n = n; q.nwp = nwp; q.E = c->E; q.slots = c->gen_slots;
             q.cn_steps = c->gen_cn_steps; q.vn_steps = c->gen_vn_steps;
-            q.row_ptr = c->d_row_ptr; q.col_edge = c->d_col_edge; q.edge_col = c->d_edge_col;
+            q.row_ptr = c->d_row_ptr; q.edge_col = c->d_edge_col;
             q.cn_desc = reinterpret_cast<const int4*>(c->d_genres);
             q.vn_desc = reinterpret_cast<const int4*>(c->d_genres + (size_t)4 * q.cn_steps * nt);
             q.pos_of_var = c->d_genres + (size_t)4 * q.cn_steps * nt + (size_t)8 * q.vn_steps * nt;
             q.edge_pos = q.pos_of_var + n;
+            q.edge_slot = q.edge_pos + c->E;
+            q.col_slot = q.edge_slot + c->E;
             q.llr = src.kind == Src::Float ? src.llr : nullptr;
             q.r = src.kind == Src::Bsc ? src.r : nullptr;
             q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
