@@ -103,6 +103,7 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
 
     // LDS addresses of the edge slots of this thread's variables: fixed for the whole decode, and
     // kept opaque so that they stay in registers instead of being re-formed as base + offset per use
+    const uint32_t lds_base = lds_address(msgb);
     uint32_t off[kLdsVpt][DV];
 #pragma unroll
     for (int v = 0; v < kLdsVpt; ++v)
@@ -121,6 +122,15 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
         return (src_r[j] == 0) ? mag : -mag;
     };
     if (t == 0) *red = 0;
+    // Early termination keeps the syndrome itself, one bit per check, and only toggles the checks of
+    // the variables whose decision changed since the previous iteration (few, after the first ones):
+    // all decisions 0 and all syndrome bits 0 is the consistent state to start from.
+    uint32_t* par = reinterpret_cast<uint32_t*>(red + 4);   // [m / 32]
+    const int mw = p.m >> 5;
+    if constexpr (EARLY) {
+        for (int w = t; w < mw; w += nt) par[w] = 0u;
+    }
+    uint32_t mydec = 0u;  // bit v: the current decision of this thread's variable v
     // beta of the first iteration: lambda + the zero-initialised alpha (LogDecoder.java:57, :70-77)
     for (int e = t; e < (int)p.E; e += nt) msg[p.edge_slot[e]] = lam_of(p.edge_col[e]) + 0.0f;
     __syncthreads();
@@ -135,6 +145,7 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
     }
 
     int iters = p.max_iters, synd = 0;
+    bool converged = false;
     for (int it = 0; it < p.max_iters; ++it) {
         // check nodes: beta -> alpha in place, two checks per step in the halves of packed registers
 #pragma unroll
@@ -166,6 +177,7 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
         for (int v = 0; v < kLdsVpt; v += 2)
 #pragma unroll
             for (int k = 0; k < DV; ++k) va[v / 2][k] = v2f{lds_load(off[v][k]), lds_load(off[v + 1][k])};
+        uint32_t newdec = 0u;
 #pragma unroll
         for (int v = 0; v < kLdsVpt; v += 2) {
             v2f g;
@@ -177,28 +189,66 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
                     lds_store(off[v + 1][k], va[v / 2][k].y);
                 }
             }
-            if (EARLY || it + 1 == p.max_iters) {
-                // "(gamma[j] < 0) ? 1 : 0", :104; q is a multiple of 64 in lane 0 and n a multiple of 64
-                const unsigned long long m0 = __ballot(g.x < 0.0f), m1 = __ballot(g.y < 0.0f);
-                if ((t & 63) == 0) {
-                    const int q0 = t + v * nt, q1 = t + (v + 1) * nt;
-                    bits[q0 >> 5] = (uint32_t)m0;
-                    bits[(q0 >> 5) + 1] = (uint32_t)(m0 >> 32);
-                    bits[q1 >> 5] = (uint32_t)m1;
-                    bits[(q1 >> 5) + 1] = (uint32_t)(m1 >> 32);
+            // "(gamma[j] < 0) ? 1 : 0", :104
+            newdec |= (g.x < 0.0f ? 1u : 0u) << v | (g.y < 0.0f ? 1u : 0u) << (v + 1);
+        }
+        if constexpr (EARLY) {
+            uint32_t changed = newdec ^ mydec;
+            mydec = newdec;
+            while (changed) {  // rare after the first iterations
+                const int v = __builtin_ctz(changed);
+                changed &= changed - 1u;
+#pragma unroll
+                for (int vv = 0; vv < kLdsVpt; ++vv) {
+                    if (vv != v) continue;
+#pragma unroll
+                    for (int k = 0; k < DV; ++k) {
+                        // slot -> syndrome bit: 2 * (pair row) + (which check of the pair); any fixed
+                        // one-to-one numbering of the checks serves
+                        const uint32_t slot = (off[vv][k] - lds_base) >> 2;
+                        const uint32_t b = 2u * (slot / (2u * DC)) + (slot & 1u);
+                        atomicXor(&par[b >> 5], 1u << (b & 31u));
+                    }
                 }
             }
-        }
-        __syncthreads();
-        if constexpr (EARLY) {
-            synd = lds_syndrome<DC>(p, bits, red, t, nt);
-            if (synd == 0) {  // LogDecoder.java:117-119
+            __syncthreads();
+            // "sumSyndro == 0" (LogDecoder.java:108-119): no bit set in any word
+            const int bad = __syncthreads_or(t < mw && par[t] != 0u);
+            if (!bad) {
                 iters = it + 1;
+                converged = true;
                 break;
             }
+        } else {
+            mydec = newdec;
+            __syncthreads();
         }
     }
-    if constexpr (!EARLY) synd = lds_syndrome<DC>(p, bits, red, t, nt);
+    // decisions -> packed words by VN position (q is a multiple of 64 in lane 0, n a multiple of 64)
+#pragma unroll
+    for (int v = 0; v < kLdsVpt; ++v) {
+        const unsigned long long mask = __ballot((mydec >> v) & 1u);
+        if ((t & 63) == 0) {
+            const int q = t + v * nt;
+            bits[q >> 5] = (uint32_t)mask;
+            bits[(q >> 5) + 1] = (uint32_t)(mask >> 32);
+        }
+    }
+    __syncthreads();
+    if constexpr (EARLY) {
+        if (!converged) {  // weight of the last iteration's syndrome: its bits are all in the first wave's reach
+            int cnt = (t < mw) ? __popc(par[t]) : 0;
+            if (t < 64) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+                if (t == 0) *red = cnt;
+            }
+            __syncthreads();
+            synd = *red;
+        }
+    } else {
+        synd = lds_syndrome<DC>(p, bits, red, t, nt);
+    }
 
     uint8_t* out = p.hard + frame * p.n;
     if ((p.n & 3) == 0) {

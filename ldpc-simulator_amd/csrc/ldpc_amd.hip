@@ -361,7 +361,8 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         const bool shape = (c->reg_dc == 6 && c->reg_dv == 3) || (c->reg_dc == 8 && c->reg_dv == 2);
         // exact tiling: 8 variables and 8 m / n checks per thread, whole wavefronts
         const int nt = n / kLdsVpt;
-        const size_t lds_bytes = ((size_t)c->E + (size_t)c->nw + 4) * sizeof(float);
+        // messages | packed decisions | accumulator | one syndrome bit per check
+        const size_t lds_bytes = ((size_t)c->E + (size_t)c->nw + 4 + (size_t)(c->m + 31) / 32) * sizeof(float);
         bool use = shape && n % (kLdsVpt * 64) == 0 && nt <= 512 && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll;
         if (const char* env = getenv("LDPC_AMD_ENGINE")) {
             if (!strcmp(env, "stream") || !strcmp(env, "generic")) use = false;
