@@ -39,6 +39,7 @@ struct LdsGenParams {
     const int* col_slot;    // [E] message slots of a variable's edges, ascending check (CSC order)
     const int* edge_col;    // [E] variable of CSR edge e
     const int* edge_slot;   // [E] message slot of CSR edge e
+    const int* col_check;   // [E] check of a variable's edges, ascending (CSC order)
     const int4* cn_desc;    // [cn_steps*nt] two checks: (first slot a, degree a, first slot b, degree b); degree 0 = none;
                             // position k of a row is kGenRowStride words after its first slot
     const int4* vn_desc;    // [vn_steps*nt][2] two variables: (j, first entry in col_slot, degree, 0) each; j = -1 = none
@@ -154,6 +155,17 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
     for (int e = t; e < (int)p.E; e += nt) msg[p.edge_slot[e]] = lam[p.edge_col[e]] + 0.0f;
     __syncthreads();
 
+    // early termination keeps the syndrome itself, one bit per check (all decisions 0 and all syndrome
+    // bits 0 is the consistent state to start from); bit 2 s + h of mydec is the current decision of
+    // variable h of this thread's item in step s
+    uint32_t* par = reinterpret_cast<uint32_t*>(red + 4);  // [ceil(m / 32)]
+    const int mw = (p.m + 31) >> 5;
+    if constexpr (EARLY) {
+        for (int w = t; w < mw; w += nt) par[w] = 0u;
+        __syncthreads();
+    }
+    uint32_t mydec = 0u;
+    bool converged = false;
     int iters = p.max_iters, synd = 0;
     for (int it = 0; it < p.max_iters; ++it) {
         // check nodes: beta -> alpha in place (LogDecoder.java:82-95)
@@ -174,6 +186,7 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
         __syncthreads();
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit (:67-79, :98-105)
         const bool write_beta = EARLY || (it + 1 < p.max_iters);
+        uint32_t newdec = 0u;
         for (int s = 0; s < p.vn_steps; ++s) {
             const int item = t + s * nt;
             const int4 va = p.vn_desc[2 * item], vb = p.vn_desc[2 * item + 1];
@@ -195,29 +208,63 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
                     g.y = g1[0];
                 }
             }
-            if (EARLY || it + 1 == p.max_iters) {
-                // "(gamma[j] < 0) ? 1 : 0", :104; decision position of the item's first variable:
-                // 128 * (item / 64) + item % 64, of its second: 64 more
-                const unsigned long long ma = __ballot(va.x >= 0 && g.x < 0.0f), mb = __ballot(vb.x >= 0 && g.y < 0.0f);
-                if (lane == 0) {  // item is a multiple of 64 here
-                    uint32_t* w = bits + 4 * (item >> 6);
-                    w[0] = (uint32_t)ma;
-                    w[1] = (uint32_t)(ma >> 32);
-                    w[2] = (uint32_t)mb;
-                    w[3] = (uint32_t)(mb >> 32);
-                }
+            // "(gamma[j] < 0) ? 1 : 0", :104
+            const uint32_t da = (va.x >= 0 && g.x < 0.0f) ? 1u : 0u, db = (vb.x >= 0 && g.y < 0.0f) ? 1u : 0u;
+            newdec |= (da | (db << 1)) << (2 * s);
+            if constexpr (EARLY) {
+                // the syndrome is kept bit by bit; a changed decision toggles the bits of its checks
+                const uint32_t ch = ((mydec >> (2 * s)) & 3u) ^ (da | (db << 1));
+                if (ch & 1u)
+                    for (int k = 0; k < va.z; ++k) {
+                        const int i = p.col_check[va.y + k];
+                        atomicXor(&par[i >> 5], 1u << (i & 31));
+                    }
+                if (ch & 2u)
+                    for (int k = 0; k < vb.z; ++k) {
+                        const int i = p.col_check[vb.y + k];
+                        atomicXor(&par[i >> 5], 1u << (i & 31));
+                    }
             }
         }
+        mydec = newdec;
         __syncthreads();
         if constexpr (EARLY) {
-            synd = lds_gen_syndrome(p, bits, red, t, nt);
-            if (synd == 0) {  // LogDecoder.java:117-119
+            uint32_t any = 0u;
+            for (int w = t; w < mw; w += nt) any |= par[w];
+            if (!__syncthreads_or(any != 0u)) {  // "sumSyndro == 0", LogDecoder.java:108-119
                 iters = it + 1;
+                converged = true;
                 break;
             }
         }
     }
-    if constexpr (!EARLY) synd = lds_gen_syndrome(p, bits, red, t, nt);
+    // decisions -> packed words; position of an item's first variable: 128 * (item / 64) + item % 64,
+    // of its second: 64 more
+    for (int s = 0; s < p.vn_steps; ++s) {
+        const int item = t + s * nt;
+        const unsigned long long ma = __ballot((mydec >> (2 * s)) & 1u), mb = __ballot((mydec >> (2 * s + 1)) & 1u);
+        if (lane == 0) {  // item is a multiple of 64 here
+            uint32_t* w = bits + 4 * (item >> 6);
+            w[0] = (uint32_t)ma;
+            w[1] = (uint32_t)(ma >> 32);
+            w[2] = (uint32_t)mb;
+            w[3] = (uint32_t)(mb >> 32);
+        }
+    }
+    __syncthreads();
+    if constexpr (EARLY) {
+        if (!converged) {  // weight of the last iteration's syndrome
+            int cnt = 0;
+            for (int w = t; w < mw; w += nt) cnt += __popc(par[w]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (lane == 0 && cnt) atomicAdd(red, cnt);
+            __syncthreads();
+            synd = *red;
+        }
+    } else {
+        synd = lds_gen_syndrome(p, bits, red, t, nt);
+    }
 
     uint8_t* out = p.hard + frame * p.n;
     for (int j = t; j < p.n; j += nt) {

@@ -55,7 +55,7 @@ struct ldpc_amd_ctx {
     int res_nt = 0;
     int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E] | edge_slot[E] | edge_pos[E]
     double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
-    // tables of the generic frame-resident engine: cn_desc | vn_desc | pos_of_var[n] | edge_pos[E] | edge_slot[E] | col_slot[E]
+    // tables of the generic frame-resident engine: cn_desc | vn_desc | pos_of_var[n] | edge_pos[E] | edge_slot[E] | col_slot[E] | col_check[E]
     int gen_nt = 0, gen_cn_steps = 0, gen_vn_steps = 0, gen_slots = 0;
     int* d_genres = nullptr;
     // timing of the last decode
@@ -248,14 +248,16 @@ int build_generic_resident_tables(ldpc_amd_ctx* c, int nt) {
     const long long E = c->E;
     const int cn_items = (m + 1) / 2, vn_items = (n + 1) / 2;
     const int cn_steps = (cn_items + nt - 1) / nt, vn_steps = (vn_items + nt - 1) / nt;
-    // layout: cn_desc int4[cn_steps*nt] | vn_desc int4[vn_steps*nt][2] | pos_of_var[n] | edge_pos[E] | edge_slot[E] | col_slot[E]
-    std::vector<int> tab((size_t)4 * cn_steps * nt + (size_t)8 * vn_steps * nt + (size_t)n + (size_t)3 * E, 0);
+    // layout: cn_desc int4[cn_steps*nt] | vn_desc int4[vn_steps*nt][2] | pos_of_var[n] | edge_pos[E] | edge_slot[E] |
+    //         col_slot[E] | col_check[E]
+    std::vector<int> tab((size_t)4 * cn_steps * nt + (size_t)8 * vn_steps * nt + (size_t)n + (size_t)4 * E, 0);
     int* cn_desc = tab.data();
     int* vn_desc = cn_desc + (size_t)4 * cn_steps * nt;
     int* pos_of_var = vn_desc + (size_t)8 * vn_steps * nt;
     int* edge_pos = pos_of_var + n;
     int* edge_slot = edge_pos + E;
     int* col_slot = edge_slot + E;
+    int* col_check = col_slot + E;
     for (int q = 0; q < 2 * vn_steps * nt; ++q) vn_desc[4 * q] = -1;
     std::vector<int> idx((size_t)std::max(m, n));
     for (int i = 0; i < m; ++i) idx[(size_t)i] = i;
@@ -293,6 +295,12 @@ int build_generic_resident_tables(ldpc_amd_ctx* c, int nt) {
     }
     for (long long e = 0; e < E; ++e) edge_pos[e] = pos_of_var[c->h_edge_col[(size_t)e]];
     for (long long t = 0; t < E; ++t) col_slot[t] = edge_slot[c->h_col_edge[(size_t)t]];
+    {
+        std::vector<int> edge_row((size_t)E);
+        for (int i = 0; i < m; ++i)
+            for (int e = c->h_row_ptr[(size_t)i]; e < c->h_row_ptr[(size_t)i + 1]; ++e) edge_row[(size_t)e] = i;
+        for (long long t = 0; t < E; ++t) col_check[t] = edge_row[(size_t)c->h_col_edge[(size_t)t]];
+    }
     if (c->d_genres) {
         LDPC_HIP(c, hipFree(c->d_genres));
         c->d_genres = nullptr;
@@ -416,12 +424,13 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         if (use) {
             if (int rc = build_generic_resident_tables(c, nt)) return rc;  // also gives the padded slot count
             nwp = 2 * c->gen_vn_steps * nt / 32;
-            lds_bytes = ((size_t)c->gen_slots + (size_t)n + (size_t)nwp + 4) * sizeof(float);
+            // messages | LLRs | packed decisions | accumulator | one syndrome bit per check
+            lds_bytes = ((size_t)c->gen_slots + (size_t)n + (size_t)nwp + 4 + (size_t)(c->m + 31) / 32) * sizeof(float);
             // up to the whole LDS of a CU: even at one workgroup per CU this engine measured 1.5x (fixed
             // iterations) to 3x (early exit) the streaming engine
             size_t lds_limit = 160 * 1024;
             if (const char* env = getenv("LDPC_AMD_GENERIC_LDS_KB")) lds_limit = (size_t)atoi(env) * 1024;  // experiments
-            use = lds_bytes <= lds_limit;
+            use = lds_bytes <= lds_limit && c->gen_vn_steps <= 16;  // 2 decision bits per step in one register
         }
         if (use) {
             LdsGenParams q{};
@@ -434,6 +443,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             q.edge_pos = q.pos_of_var + n;
             q.edge_slot = q.edge_pos + c->E;
             q.col_slot = q.edge_slot + c->E;
+            q.col_check = q.col_slot + c->E;
             q.llr = src.kind == Src::Float ? src.llr : nullptr;
             q.r = src.kind == Src::Bsc ? src.r : nullptr;
             q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
