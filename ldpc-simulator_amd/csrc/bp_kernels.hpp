@@ -562,9 +562,8 @@ __device__ __forceinline__ void vn_dispatch(int d, float* msg, const float* lamr
 // flight while it computes, and the wait for those loads never has to wait for the stores issued
 // after them (vector memory operations retire in issue order).
 template <int FPL, int D, bool FIRST>
-__device__ __forceinline__ void cn_load(const BpParams& p, const float* msg, const float* lam, int i,
-                                        float (&b)[D][FPL]) {
-    const long long e0 = (long long)i * D;
+__device__ __forceinline__ void cn_load_at(const BpParams& p, const float* msg, const float* lam, long long e0,
+                                           float (&b)[D][FPL]) {
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         if constexpr (FIRST) ldv<FPL>(lam + (long long)p.edge_col[e0 + k] * p.lam_row, b[k]);
@@ -573,7 +572,7 @@ __device__ __forceinline__ void cn_load(const BpParams& p, const float* msg, con
 }
 
 template <int FPL, int D, int RULE, bool FIRST>
-__device__ __forceinline__ void cn_finish(const BpParams& p, float* msg, int i, float (&b)[D][FPL]) {
+__device__ __forceinline__ void cn_finish_at(const BpParams& p, float* msg, long long e0, float (&b)[D][FPL]) {
     if constexpr (FIRST) {
 #pragma unroll
         for (int k = 0; k < D; ++k)
@@ -581,10 +580,92 @@ __device__ __forceinline__ void cn_finish(const BpParams& p, float* msg, int i, 
             for (int f = 0; f < FPL; ++f) b[k][f] += 0.0f;  // lambda + the zero-initialised alpha of :57
     }
     cn_compute<FPL, D, RULE>(b);
-    const long long e0 = (long long)i * D;
 #pragma unroll
     for (int k = 0; k < D; ++k) stv<FPL>(msg + (e0 + k) * p.msg_row, b[k]);
 }
+
+template <int FPL, int D, bool FIRST>
+__device__ __forceinline__ void cn_load(const BpParams& p, const float* msg, const float* lam, int i,
+                                        float (&b)[D][FPL]) {
+    cn_load_at<FPL, D, FIRST>(p, msg, lam, (long long)i * D, b);
+}
+
+template <int FPL, int D, int RULE, bool FIRST>
+__device__ __forceinline__ void cn_finish(const BpParams& p, float* msg, int i, float (&b)[D][FPL]) {
+    cn_finish_at<FPL, D, RULE, FIRST>(p, msg, (long long)i * D, b);
+}
+
+// Rows whose loads a wave issues together before it uses the first of them (at most 48 message
+// registers in flight): what hides the memory latency when a wave's rows are short.
+template <int FPL, int D> constexpr int rows_group() {
+    return 48 / (D * FPL) >= 4 ? 4 : 48 / (D * FPL) >= 1 ? 48 / (D * FPL) : 1;
+}
+// ... for codes of any degrees, where the row addresses are not multiples of one constant and take
+// registers of their own: 24 message registers per group of checks, 48 registers of messages, 64-bit
+// edge offsets and channel LLRs per group of variables
+template <int FPL, int D> constexpr int rows_group_any() {
+    return 24 / (D * FPL) >= 4 ? 4 : 24 / (D * FPL) >= 1 ? 24 / (D * FPL) : 1;
+}
+template <int FPL, int D> constexpr int cols_group() {
+    return 48 / (D * (FPL + 2) + FPL) >= 4 ? 4 : 48 / (D * (FPL + 2) + FPL) >= 1 ? 48 / (D * (FPL + 2) + FPL) : 1;
+}
+
+// Any degrees: checks i0 .. i1-1.  A run of consecutive checks of one degree (the Z rows of a block
+// row of a quasi-cyclic H, or a regular stretch of any H) is taken as a group like the rows of a
+// regular code; everything else goes row by row.  Same per-row arithmetic either way.
+template <int FPL, int D, int RULE, bool FIRST>
+__device__ __forceinline__ int cn_run(const BpParams& p, float* msg, const float* lam, int i, int i1, int e0) {
+    constexpr int G = rows_group_any<FPL, D>();
+    if constexpr (G > 1) {
+        bool run = i + G <= i1;
+        if (run) {
+#pragma unroll
+            for (int g = 2; g <= G; ++g) run = run && (p.row_ptr[i + g] - e0 == g * D);
+        }
+        if (run) {
+            float buf[G][D][FPL];
+#pragma unroll
+            for (int g = 0; g < G; ++g) cn_load_at<FPL, D, FIRST>(p, msg, lam, (long long)e0 + g * D, buf[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                cn_finish_at<FPL, D, RULE, FIRST>(p, msg, (long long)e0 + g * D, buf[g]);
+                __builtin_amdgcn_sched_barrier(0);  // one row's temporaries at a time
+            }
+            return G;
+        }
+    }
+    cn_row<FPL, D, RULE, FIRST>(msg + (long long)e0 * p.msg_row, lam, p.edge_col + e0, p.msg_row, p.lam_row);
+    return 1;
+}
+
+#define LDPC_RUN_CN(D)                                                         \
+    case D:                                                                    \
+        if constexpr (D <= (FPL == 1 ? kRegDegCn : kRegDegFpl4)) {             \
+            i += cn_run<FPL, D, RULE, FIRST>(p, msg, lam, i, i1, e0);          \
+            continue;                                                          \
+        }                                                                      \
+        break;
+
+template <int FPL, int RULE, bool FIRST>
+__device__ __forceinline__ void cn_rows_any(const BpParams& p, float* msg, const float* lam, int i0, int i1, float* lds,
+                                            int lane) {
+    int i = i0;
+    while (i < i1) {
+        const int e0 = p.row_ptr[i];
+        const int d = p.row_ptr[i + 1] - e0;
+        switch (d) {
+            LDPC_RUN_CN(1) LDPC_RUN_CN(2) LDPC_RUN_CN(3) LDPC_RUN_CN(4) LDPC_RUN_CN(5) LDPC_RUN_CN(6)
+            LDPC_RUN_CN(7) LDPC_RUN_CN(8) LDPC_RUN_CN(9) LDPC_RUN_CN(10) LDPC_RUN_CN(11) LDPC_RUN_CN(12)
+            LDPC_RUN_CN(13) LDPC_RUN_CN(14) LDPC_RUN_CN(15) LDPC_RUN_CN(16) LDPC_RUN_CN(17) LDPC_RUN_CN(18)
+            LDPC_RUN_CN(19) LDPC_RUN_CN(20) LDPC_RUN_CN(21) LDPC_RUN_CN(22) LDPC_RUN_CN(23) LDPC_RUN_CN(24)
+            default: break;
+        }
+        cn_dispatch<FPL, RULE, FIRST>(d, msg + (long long)e0 * p.msg_row, lam, p.edge_col + e0, p.msg_row, p.lam_row, lds,
+                                      p.lds_maxd, lane);
+        ++i;
+    }
+}
+#undef LDPC_RUN_CN
 
 template <int FPL, int D, int RULE, bool FIRST>
 __device__ __forceinline__ void cn_sweep_regular(const BpParams& p, float* msg, const float* lam) {
@@ -607,12 +688,7 @@ __device__ __forceinline__ void cn_sweep(const BpParams& p, float* msg, const fl
         cn_sweep_regular<FPL, DC, RULE, FIRST>(p, msg, lam);
         return;
     }
-    for (int i = 0; i < p.m; ++i) {
-        const int e0 = p.row_ptr[i];
-        const int d = p.row_ptr[i + 1] - e0;
-        cn_dispatch<FPL, RULE, FIRST>(d, msg + (long long)e0 * p.msg_row, lam, p.edge_col + e0, p.msg_row, p.lam_row, lds,
-                                      p.lds_maxd, lane);
-    }
+    cn_rows_any<FPL, RULE, FIRST>(p, msg, lam, 0, p.m, lds, lane);
 }
 
 // beta for the next iteration + tentative decisions of this one (LogDecoder.java:67-79, :98-105)
@@ -624,13 +700,18 @@ struct VnBuf {
 };
 
 template <int FPL, int D>
-__device__ __forceinline__ void vn_load(const BpParams& p, const float* msg, const float* lam, int j, VnBuf<FPL, D>& b) {
-    const long long c0 = (long long)j * D;
+__device__ __forceinline__ void vn_load_at(const BpParams& p, const float* msg, const float* lam, int j, long long c0,
+                                           VnBuf<FPL, D>& b) {
 #pragma unroll
     for (int k = 0; k < D; ++k) b.off[k] = (long long)p.col_edge[c0 + k] * p.msg_row;
 #pragma unroll
     for (int k = 0; k < D; ++k) ldv<FPL>(msg + b.off[k], b.a[k]);
     ldv<FPL>(lam + (long long)j * p.lam_row, b.lam);
+}
+
+template <int FPL, int D>
+__device__ __forceinline__ void vn_load(const BpParams& p, const float* msg, const float* lam, int j, VnBuf<FPL, D>& b) {
+    vn_load_at<FPL, D>(p, msg, lam, j, (long long)j * D, b);
 }
 
 template <int FPL, int D>
@@ -670,19 +751,57 @@ __device__ __forceinline__ void vn_sweep_regular(const BpParams& p, float* msg, 
     if (j < n) vn_finish<FPL, D>(p, msg, bits, j, write_beta, A, acc);
 }
 
-template <int FPL, int DV>
-__device__ __forceinline__ void vn_sweep(const BpParams& p, float* msg, const float* lam, uint32_t* bits,
-                                         bool write_beta, float* lds, int lane) {
-    if constexpr (DV > 0) {
-        vn_sweep_regular<FPL, DV>(p, msg, lam, bits, write_beta);
-        return;
+// Any degrees: variables j0 .. j1-1 (j0 a multiple of 32, acc the decision bits collected so far), with runs
+// of one degree grouped like the checks in cn_rows_any.
+template <int FPL, int D>
+__device__ __forceinline__ int vn_run(const BpParams& p, float* msg, const float* lam, uint32_t* bits, bool write_beta,
+                                      int j, int j1, int c0, uint32_t (&acc)[FPL]) {
+    constexpr int G = cols_group<FPL, D>();
+    bool run = G > 1 && j + G <= j1;
+    if (run) {
+#pragma unroll
+        for (int g = 2; g <= G; ++g) run = run && (p.col_ptr[j + g] - c0 == g * D);
     }
+    if (run) {
+        VnBuf<FPL, D> buf[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) vn_load_at<FPL, D>(p, msg, lam, j + g, (long long)c0 + g * D, buf[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            vn_finish<FPL, D>(p, msg, bits, j + g, write_beta, buf[g], acc);
+            __builtin_amdgcn_sched_barrier(0);  // one variable's temporaries at a time
+        }
+        return G;
+    }
+    VnBuf<FPL, D> one;
+    vn_load_at<FPL, D>(p, msg, lam, j, (long long)c0, one);
+    vn_finish<FPL, D>(p, msg, bits, j, write_beta, one, acc);
+    return 1;
+}
+
+#define LDPC_RUN_VN(D)                                                               \
+    case D:                                                                          \
+        if constexpr (D <= (FPL == 1 ? kRegDegVn : kRegDegFpl4)) {                   \
+            j += vn_run<FPL, D>(p, msg, lam, bits, write_beta, j, j1, c0, acc);      \
+            continue;                                                                \
+        }                                                                            \
+        break;
+
+template <int FPL>
+__device__ __forceinline__ void vn_cols_any(const BpParams& p, float* msg, const float* lam, uint32_t* bits,
+                                            bool write_beta, int j0, int j1, float* lds, int lane) {
     uint32_t acc[FPL];
 #pragma unroll
     for (int f = 0; f < FPL; ++f) acc[f] = 0u;
-    for (int j = 0; j < p.n; ++j) {
+    int j = j0;
+    while (j < j1) {
         const int c0 = p.col_ptr[j];
         const int d = p.col_ptr[j + 1] - c0;
+        switch (d) {
+            LDPC_RUN_VN(1) LDPC_RUN_VN(2) LDPC_RUN_VN(3) LDPC_RUN_VN(4) LDPC_RUN_VN(5) LDPC_RUN_VN(6)
+            LDPC_RUN_VN(7) LDPC_RUN_VN(8) LDPC_RUN_VN(9) LDPC_RUN_VN(10) LDPC_RUN_VN(11) LDPC_RUN_VN(12)
+            default: break;
+        }
         float g[FPL];
         vn_dispatch<FPL>(d, msg, lam + (long long)j * p.lam_row, p.col_edge + c0, p.msg_row, write_beta, g, lds,
                          p.lds_maxd, lane);
@@ -693,7 +812,19 @@ __device__ __forceinline__ void vn_sweep(const BpParams& p, float* msg, const fl
 #pragma unroll
             for (int f = 0; f < FPL; ++f) acc[f] = 0u;
         }
+        ++j;
     }
+}
+#undef LDPC_RUN_VN
+
+template <int FPL, int DV>
+__device__ __forceinline__ void vn_sweep(const BpParams& p, float* msg, const float* lam, uint32_t* bits,
+                                         bool write_beta, float* lds, int lane) {
+    if constexpr (DV > 0) {
+        vn_sweep_regular<FPL, DV>(p, msg, lam, bits, write_beta);
+        return;
+    }
+    vn_cols_any<FPL>(p, msg, lam, bits, write_beta, 0, p.n, lds, lane);
 }
 
 // number of unsatisfied checks of the packed decisions (sumSyndro, LogDecoder.java:108-116)

@@ -36,14 +36,11 @@ __device__ __forceinline__ bool rows_lane_active(const RowsParams& p, int tile, 
     return true;
 }
 
-// Regular codes (DC / DV > 0 = the degree of every check / variable): a wave's rows are handled in
-// groups whose loads are all issued before the first of them is used, so that a small batch, where a
-// launch is a few thousand short waves and nothing else hides the memory latency, waits once per
-// group instead of once per row.  Same per-row arithmetic, same bits.
-template <int FPL, int D> constexpr int rows_group() {  // at most 48 message registers in flight
-    return 48 / (D * FPL) >= 4 ? 4 : 48 / (D * FPL) >= 1 ? 48 / (D * FPL) : 1;
-}
-
+// A wave's rows are handled in groups whose loads are all issued before the first of them is used
+// (rows_group / cols_group in bp_kernels.hpp), so that a small batch, where a launch is a few thousand
+// short waves and nothing else hides the memory latency, waits once per group instead of once per row:
+// every group of a regular code (DC / DV > 0 = the degree of every check / variable), runs of equal
+// degree otherwise.  Same per-row arithmetic, same bits.
 template <int FPL, int RULE, bool FIRST, int DC>
 __global__ void __launch_bounds__(256, 4) rows_cn_kernel(RowsParams p) {
     extern __shared__ float lds_all[];
@@ -69,12 +66,7 @@ __global__ void __launch_bounds__(256, 4) rows_cn_kernel(RowsParams p) {
                     if (i + g < i1) cn_finish<FPL, DC, RULE, FIRST>(p.b, msg, i + g, buf[g]);
             }
         } else {
-            for (int i = i0; i < i1; ++i) {
-                const int e0 = p.b.row_ptr[i];
-                const int d = p.b.row_ptr[i + 1] - e0;
-                cn_dispatch<FPL, RULE, FIRST>(d, msg + (long long)e0 * p.b.msg_row, lam, p.b.edge_col + e0, p.b.msg_row,
-                                              p.b.lam_row, lds, p.b.lds_maxd, lane);
-            }
+            cn_rows_any<FPL, RULE, FIRST>(p.b, msg, lam, i0, i1, lds, lane);
         }
     }
 }
@@ -109,20 +101,7 @@ __global__ void __launch_bounds__(256, 4) rows_vn_kernel(RowsParams p, int write
         }
         return;
     }
-    for (int j = j0; j < j1; ++j) {
-        const int c0 = p.b.col_ptr[j];
-        const int d = p.b.col_ptr[j + 1] - c0;
-        float g[FPL];
-        vn_dispatch<FPL>(d, msg, lam + (long long)j * p.b.lam_row, p.b.col_edge + c0, p.b.msg_row, write_beta != 0, g,
-                         lds, p.b.lds_maxd, lane);
-#pragma unroll
-        for (int f = 0; f < FPL; ++f) acc[f] |= (g[f] < 0.0f ? 1u : 0u) << (j & 31);  // "(gamma[j] < 0) ? 1 : 0", :104
-        if ((j & 31) == 31 || j == p.b.n - 1) {
-            stw<FPL>(bits + (long long)(j >> 5) * p.b.bits_row, acc);
-#pragma unroll
-            for (int f = 0; f < FPL; ++f) acc[f] = 0u;
-        }
-    }
+    vn_cols_any<FPL>(p.b, msg, lam, bits, write_beta != 0, j0, j1, lds, lane);
 }
 
 template <int FPL>
