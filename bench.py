@@ -266,6 +266,7 @@ def main():
     if world == 1 and kernel == "bp_lds_kernel" and not args.no_stream_leg:
         # the same batch once through the frame-major HBM streaming engine, for the HBM roofline figure
         os.environ["LDPC_AMD_ENGINE"] = "stream"
+        os.environ["LDPC_AMD_ROWS"] = "0"  # the one-launch streaming kernel: one launch = one profiler row
         for timed in (False, True):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -274,6 +275,7 @@ def main():
             torch.cuda.synchronize()
             t2 = time.perf_counter()
         os.environ.pop("LDPC_AMD_ENGINE", None)
+        os.environ.pop("LDPC_AMD_ROWS", None)
         out["streaming_engine"] = {
             "value": F * k / (t2 - t1) / 1e9, "unit": "Gbit/s", "ms_per_step": (t2 - t1) * 1e3,
             "roofline": {"bound": "hbm", "achieved": F * b_frame / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -494,6 +494,17 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     long long max_tiles = (long long)(limit / per_tile);
     if (max_tiles < 1) max_tiles = 1;
     if (max_tiles > (1ll << 30)) max_tiles = 1ll << 30;
+    // layout 0: [tile][row][T]  (a tile's rows are contiguous)
+    // layout 1: [row][tile][T]  (the same row of neighbouring tiles is contiguous)
+    int layout = 0;
+    if (const char* env = getenv("LDPC_AMD_LAYOUT")) layout = atoi(env) ? 1 : 0;
+    // Every sweep is its own launch over (tile, row chunk) pairs, cut as finely as the packed decision
+    // words allow (32 variables per wave): short uniform waves walk through the tiles in address order,
+    // a wave whose frames have all converged ends at once, and a batch of any size fills the chip.
+    // LDPC_AMD_ROWS=0 selects the other streaming kernel, one wave per tile for the whole decode.
+    bool by_rows = layout == 0 && fpl != 2;
+    if (const char* env = getenv("LDPC_AMD_ROWS")) by_rows = by_rows && atoi(env) != 0;
+    if (by_rows) max_tiles = std::min<long long>(max_tiles, 65535);  // tiles are the grid's y dimension
     const long long rounds = (tiles_total + max_tiles - 1) / max_tiles;
     const long long tiles_per_round = (tiles_total + rounds - 1) / rounds;
     const size_t need = per_tile * (size_t)tiles_per_round;
@@ -516,10 +527,6 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     BpParams p{};
     p.m = c->m; p.n = n; p.nw = c->nw;
     p.row_ptr = c->d_row_ptr; p.edge_col = c->d_edge_col; p.col_ptr = c->d_col_ptr; p.col_edge = c->d_col_edge;
-    // layout 0: [tile][row][T]  (a tile's rows are contiguous)
-    // layout 1: [row][tile][T]  (the same row of neighbouring tiles is contiguous)
-    int layout = 0;
-    if (const char* env = getenv("LDPC_AMD_LAYOUT")) layout = atoi(env) ? 1 : 0;
     if (layout == 0) {
         p.msg_row = p.lam_row = p.bits_row = T;
         p.msg_tile = c->E * T; p.lam_tile = (long long)n * T; p.bits_tile = (long long)c->nw * T;
@@ -538,13 +545,11 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     if (const char* env = getenv("LDPC_AMD_SKIP")) p.skip = atoi(env);  // timing experiments only
     bool pipelined = true;
     if (const char* env = getenv("LDPC_AMD_NOPIPE")) pipelined = atoi(env) == 0;  // A/B: per-row dispatch kernels
-    // Too few tiles to give every CU its own: split every sweep over row chunks, one launch per sweep.
-    bool by_rows = tiles_per_round < 2048 && tiles_per_round <= 65535 && layout == 0 && fpl != 2;
-    if (const char* env = getenv("LDPC_AMD_ROWS")) by_rows = atoi(env) != 0 && tiles_per_round <= 65535 && layout == 0 && fpl != 2;
     int chunks = 1, rows_per_chunk = c->m, vars_per_chunk = (n + 31) / 32 * 32;
     if (by_rows) {
-        chunks = (int)std::min<long long>((8192 + tiles_per_round - 1) / tiles_per_round, 4096);
-        chunks = std::max(1, std::min(chunks, std::max(1, std::min(c->m / 4, n / 32))));
+        chunks = std::max(1, std::min(4096, std::min(c->m / 4, n / 32)));
+        if (const char* env = getenv("LDPC_AMD_ROWS_WAVES"))  // experiments: waves per launch
+            chunks = (int)std::max<long long>(1, std::min<long long>(chunks, (std::max(256, atoi(env)) + tiles_per_round - 1) / tiles_per_round));
         rows_per_chunk = (c->m + chunks - 1) / chunks;
         vars_per_chunk = ((n + chunks - 1) / chunks + 31) / 32 * 32;
         c->last_kernel = "rows_cn_kernel";

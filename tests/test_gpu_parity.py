@@ -197,7 +197,7 @@ def test_batch_split_and_rerun_invariance(c2, oracle):
         assert (x == y).all()
 
 
-def test_engines_return_identical_bits(c1, c2, oracle, engine):
+def test_engines_return_identical_bits(pkg, c1, c2, oracle, engine):
     """Both engines run the same arithmetic in the same order, so their outputs are equal bit for
     bit, converged or not."""
     if engine != "resident":
@@ -219,6 +219,25 @@ def test_engines_return_identical_bits(c1, c2, oracle, engine):
             os.environ.pop("LDPC_AMD_ENGINE", None)
             os.environ.pop("LDPC_AMD_ROWS", None)
             assert (a[2] > 0).any()
+    # an irregular quasi-cyclic code: runs of equal-degree rows (grouped loads) next to single rows
+    _, (m, n, rows, cols) = pkg.codes.nr_bg1_shaped(z=8, seed=5)
+    dec = pkg.Decoder(m, n, rows, cols)
+    llr = oracle.gen_awgn_llr(m, n, 1.0, seed=13, first_frame=0, frames=700)
+    for early, L in ((True, 20), (False, 7)):
+        a = dec.decode_batch(llr, L, early)
+        assert dec.last_decode_kernel() == "bp_lds_gen_kernel"
+        for rows_mode, kernel in (("0", "bp_decode_kernel"), ("1", "rows_cn_kernel")):
+            os.environ["LDPC_AMD_ENGINE"] = "stream"
+            os.environ["LDPC_AMD_ROWS"] = rows_mode
+            try:
+                b = dec.decode_batch(llr, L, early)
+            finally:
+                os.environ.pop("LDPC_AMD_ENGINE", None)
+                os.environ.pop("LDPC_AMD_ROWS", None)
+            assert dec.last_decode_kernel() == kernel
+            for x, y in zip(a, b):
+                assert (x == y).all(), (early, L, kernel)
+        assert (a[2] > 0).any()
 
 
 def test_irregular_degrees_register_and_lds_paths(pkg, oracle, engine):
