@@ -205,10 +205,16 @@ int ldpc_amd_simulate(ldpc_amd_ctx* ctx, int32_t channel, double param, uint64_t
 int ldpc_amd_last_decode_timing(ldpc_amd_ctx* ctx, int32_t* launches, double* kernel_ms, int64_t* frames);
 
 /*
- * Name of the message-passing kernel the most recent decode ran: "bp_lds_kernel" (frame-resident:
- * a regular code whose messages fit in LDS; one workgroup per frame, messages never leave the CU) or
- * "bp_decode_kernel" (frame-major streaming through HBM: any code).  The environment variable
- * LDPC_AMD_ENGINE=stream forces the second.  Both return identical bits.
+ * Name of the message-passing kernel the most recent decode ran.  Frame-resident engines (one
+ * workgroup per frame, the messages stay in the CU's LDS for all iterations): "bp_lds_kernel" (regular
+ * (6,3) and (8,2) codes) and "bp_lds_gen_kernel" (any code whose messages fit in LDS).  Frame-major
+ * streaming through HBM, for any code: "bp_nodes_kernel" (a batch of a few frames: one cooperative
+ * launch, one thread per node), "rows_cn_kernel" (one launch per sweep; for the timing call
+ * above, one "launch" is then the whole sequence of sweeps of a round) and "bp_decode_kernel" (all
+ * iterations in one launch).  Environment: LDPC_AMD_ENGINE=stream turns the resident engines off,
+ * LDPC_AMD_ENGINE=generic the specialised one; LDPC_AMD_ROWS=0 selects the one-launch streaming
+ * kernel, LDPC_AMD_NODES=0 / 1 turns the node-parallel kernel off / on for every batch of at most 32
+ * frames.  All of them return identical bits.
  */
 const char* ldpc_amd_last_decode_kernel(const ldpc_amd_ctx* ctx);
 

@@ -17,6 +17,7 @@
 #include "bp_kernels.hpp"
 #include "bp_lds.hpp"
 #include "bp_lds_gen.hpp"
+#include "bp_nodes.hpp"
 #include "bp_rows.hpp"
 #include "io_kernels.hpp"
 
@@ -57,6 +58,8 @@ struct ldpc_amd_ctx {
     double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
     // tables of the generic frame-resident engine: cn_desc | vn_desc | pos_of_var[n] | edge_pos[E] | edge_slot[E] | col_slot[E] | col_check[E]
     int gen_nt = 0, gen_cn_steps = 0, gen_vn_steps = 0, gen_slots = 0;
+    // node-parallel cooperative engine: blocks that can be resident at once (0: not asked yet, -1: not available)
+    int nodes_blocks = 0;
     int* d_genres = nullptr;
     // timing of the last decode
     std::vector<hipEvent_t> ev;
@@ -468,6 +471,80 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             return LDPC_AMD_OK;
         }
     }
+    // Node-parallel cooperative engine: a batch of at most 32 frames of a code the resident engines do
+    // not take runs in one launch with one thread per node (a lane per frame would leave the chip empty).
+    {
+        bool use = frames <= kNodesMaxFrames && c->m > 0 && c->max_dc <= kNodesMaxDc && c->max_dv <= kNodesMaxDv &&
+                   c->nodes_blocks >= 0;
+        if (const char* env = getenv("LDPC_AMD_ENGINE")) {
+            if (!strcmp(env, "stream")) use = false;
+        }
+        // Per iteration this engine costs two grid barriers (about 20 us) plus about 64 ns per 1000 edges of
+        // the batch (gathers of single words); the sweep launches cost about 100 us of launches plus the
+        // longest wave's chain of dependent nodes, 32 variables of the largest degree (measured on an
+        // NR-BG1-sized code and on a (3,6) code of n = 64800: break-even at 32 and at 7 frames).
+        use = use && 20.0 + 6.4e-5 * (double)frames * (double)c->E < 100.0 + 5.8 * c->max_dv;
+        if (const char* env = getenv("LDPC_AMD_NODES")) {  // 0: never, 1: whenever the batch and the degrees allow
+            use = atoi(env) != 0 && frames <= kNodesMaxFrames && c->m > 0 && c->max_dc <= kNodesMaxDc &&
+                  c->max_dv <= kNodesMaxDv && c->nodes_blocks >= 0;
+            if (const char* eng = getenv("LDPC_AMD_ENGINE")) {
+                if (!strcmp(eng, "stream")) use = false;
+            }
+        }
+        if (use && c->nodes_blocks == 0) {
+            int coop = 0, blocks = 0;
+            LDPC_HIP(c, hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device));
+            if (coop) LDPC_HIP(c, bp_nodes_resident_blocks(&blocks));
+            c->nodes_blocks = blocks > 0 ? blocks : -1;
+            use = c->nodes_blocks > 0;
+        }
+        if (use) {
+            const size_t F = (size_t)frames;
+            const size_t need = F * ((size_t)c->E + (size_t)n + (size_t)max_iters) * sizeof(float);
+            if (c->ws_bytes < need) {
+                if (c->ws) {
+                    LDPC_HIP(c, hipFree(c->ws));
+                    c->ws = nullptr;
+                    c->ws_bytes = 0;
+                }
+                LDPC_HIP(c, hipMalloc(&c->ws, need));
+                c->ws_bytes = need;
+            }
+            NodesParams q{};
+            q.m = c->m; q.n = n; q.E = c->E;
+            q.row_ptr = c->d_row_ptr; q.edge_col = c->d_edge_col; q.col_ptr = c->d_col_ptr; q.col_edge = c->d_col_edge;
+            q.llr = src.kind == Src::Float ? src.llr : nullptr;
+            q.r = src.kind == Src::Bsc ? src.r : nullptr;
+            q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
+            q.scale = (float)llr_scale(c);
+            q.frames = (int)frames; q.max_iters = max_iters; q.early = early ? 1 : 0;
+            q.msg = (float*)c->ws;
+            q.lam = q.msg + F * (size_t)c->E;
+            q.synd_acc = (int32_t*)(q.lam + F * (size_t)n);
+            q.hard = d_hard; q.out_iters = d_iters; q.out_synd = d_synd;
+            LDPC_HIP(c, hipMemsetAsync(q.synd_acc, 0, F * (size_t)max_iters * sizeof(int32_t), s));
+            NodesLaunch l;
+            l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
+                     : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
+            // the grid-wide barrier costs about 0.1 us per block, the phases shrink with the blocks they are
+            // spread over: measured optimum near 64 blocks for one frame, 128 for eight
+            l.max_blocks = std::min(c->nodes_blocks, 48 + 16 * (int)frames); l.stream = s;
+            if (const char* env = getenv("LDPC_AMD_NODES_BLOCKS"))  // experiments: a smaller grid
+                l.max_blocks = std::max(1, std::min(c->nodes_blocks, atoi(env)));
+            while (c->ev.size() < 2) {
+                hipEvent_t e;
+                LDPC_HIP(c, hipEventCreate(&e));
+                c->ev.push_back(e);
+            }
+            LDPC_HIP(c, hipEventRecord(c->ev[0], s));
+            LDPC_HIP(c, bp_nodes_launch(l, q));
+            LDPC_HIP(c, hipEventRecord(c->ev[1], s));
+            c->timed_launches = 1;
+            c->timed_frames = frames;
+            c->last_kernel = "bp_nodes_kernel";
+            return LDPC_AMD_OK;
+        }
+    }
     const int maxdeg = std::max(c->max_dc, c->max_dv);
     if (maxdeg > kLdsMaxDegree) return fail(c, LDPC_AMD_ELIMIT, "node degree above 128 is not supported");
     int fpl = (!early && maxdeg <= kRegDegFpl4) ? 4 : 1;
@@ -722,7 +799,7 @@ int ldpc_amd_create(int32_t m, int32_t n, int64_t nnz, const int32_t* row_idx, c
     if (bp_generic_params_bytes() != sizeof(BpParams) || bp_6_3_params_bytes() != sizeof(BpParams) ||
         bp_8_2_params_bytes() != sizeof(BpParams) || bp_lds_6_3_params_bytes() != sizeof(LdsParams) ||
         bp_lds_8_2_params_bytes() != sizeof(LdsParams) || bp_lds_gen_params_bytes() != sizeof(LdsGenParams) ||
-        bp_rows_params_bytes() != sizeof(RowsParams))
+        bp_rows_params_bytes() != sizeof(RowsParams) || bp_nodes_params_bytes() != sizeof(NodesParams))
         return fail(nullptr, LDPC_AMD_EHIP, "create: the library was linked from objects built against different headers");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

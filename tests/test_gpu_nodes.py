@@ -1,0 +1,98 @@
+"""The node-parallel cooperative engine (very small batches of codes that do not live in LDS): against the
+double-precision oracle, and bit for bit against the row-parallel sweeps on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("LDPC_AMD_ENGINE", "LDPC_AMD_ROWS", "LDPC_AMD_NODES", "LDPC_AMD_GENERIC_LDS_KB")
+
+
+@pytest.fixture(autouse=True)
+def clean_env():
+    old = {k: os.environ.get(k) for k in KEYS}
+    for k in KEYS:
+        os.environ.pop(k, None)
+    yield
+    for k in KEYS:
+        os.environ.pop(k, None)
+        if old[k] is not None:
+            os.environ[k] = old[k]
+
+
+def _syndrome_weight_sparse(m, rows, cols, hard):
+    w = np.zeros((hard.shape[0], m), np.int64)
+    np.add.at(w, (slice(None), rows), hard[:, cols].astype(np.int64))
+    return (w % 2).sum(axis=1)
+
+
+def _both(dec, call):
+    """The same decode through the node-parallel engine and through the sweep launches."""
+    os.environ["LDPC_AMD_NODES"] = "1"
+    a = call()
+    assert dec.last_decode_kernel() == "bp_nodes_kernel"
+    os.environ["LDPC_AMD_NODES"] = "0"
+    b = call()
+    assert dec.last_decode_kernel() == "rows_cn_kernel"
+    os.environ.pop("LDPC_AMD_NODES")
+    return a, b
+
+
+def test_small_irregular_code_against_the_oracle(pkg, oracle):
+    """NR-BG1-shaped code at a small lifting size (degrees 3..19 / 1..30), kept out of the resident
+    engines: every check-node rule, LLR and hard-word input, 1 to 32 frames, early exit and fixed."""
+    os.environ["LDPC_AMD_GENERIC_LDS_KB"] = "0"
+    _, (m, n, rows, cols) = pkg.codes.nr_bg1_shaped(z=8, seed=3)
+    g = oracle.Graph(m, n, rows, cols)
+    dec = pkg.Decoder(m, n, rows, cols)
+    for F, ebn0, early, L in ((1, 2.0, True, 30), (5, 1.0, True, 20), (32, 2.5, True, 40), (32, 1.0, False, 6),
+                              (7, 3.0, True, 1), (3, 0.0, False, 1)):
+        llr = oracle.gen_awgn_llr(m, n, ebn0, seed=21 + F, first_frame=0, frames=F)
+        got, rows_out = _both(dec, lambda: dec.decode_batch(llr, L, early))
+        for x, y in zip(got, rows_out):
+            assert (x == y).all(), (F, early, L)
+        want = g.decode_llr_batch(llr, L, early)
+        for x, y in zip(got, want):
+            assert (x == y).all(), (F, early, L)
+        assert (_syndrome_weight_sparse(m, rows, cols, got[0]) == got[2]).all()
+    # hard received words with the reference's parity LLRs (LogDecoder.java:45-54)
+    r = oracle.gen_bsc(m, n, oracle.CH_BSC_INFO, 0.03, seed=5, first_frame=0, frames=20)
+    got, rows_out = _both(dec, lambda: dec.decode_bsc_batch(r, 0.03, 50, oracle.LLR_PARITY_LN1E20, True))
+    for x, y in zip(got, rows_out):
+        assert (x == y).all()
+    lam = np.stack([oracle.bsc_llr(m, n, r[f], 0.03, oracle.LLR_PARITY_LN1E20) for f in range(20)]).astype(np.float32)
+    want = g.decode_llr_batch(lam, 50, True)
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all() and (got[2] == want[2]).all()
+    # normalised min-sum (MinSumDecoder.java:79-93)
+    dec.set_cn_rule(pkg.capi.CN_MINSUM)
+    llr = oracle.gen_awgn_llr(m, n, 2.0, seed=9, first_frame=0, frames=16)
+    got, rows_out = _both(dec, lambda: dec.decode_batch(llr, 25, True))
+    for x, y in zip(got, rows_out):
+        assert (x == y).all()
+    assert (_syndrome_weight_sparse(m, rows, cols, got[0]) == got[2]).all()
+    dec.close()
+
+
+def test_bg1_sized_and_long_codes_identical_to_the_sweeps(pkg):
+    """The two codes this engine is for (too large for LDS): identical outputs, and the engine is the
+    default choice for a single frame."""
+    import torch
+    for code, ebn0, L in ((pkg.codes.nr_bg1_shaped(z=384, seed=1)[1], 1.5, 30),
+                          (pkg.codes.regular_ldpc(64800, 3, 6, 1), 1.6, 40)):
+        m, n, rows, cols = code
+        dec = pkg.Decoder(m, n, rows, cols)
+        for F, early in ((1, True), (6, True), (4, False)):
+            d_llr = torch.empty((F, n), dtype=torch.float32, device="cuda")
+            dec.gen_awgn_llr_dev(ebn0, 17, 0, F, d_llr.data_ptr())
+            llr = d_llr.cpu().numpy()
+            a, b = _both(dec, lambda: dec.decode_batch(llr, L if early else 7, early))
+            for x, y in zip(a, b):
+                assert (x == y).all(), (n, F, early)
+            assert (_syndrome_weight_sparse(m, rows, cols, a[0]) == a[2]).all()
+            if early:
+                assert (a[1] < L).any()
+        dec.decode_batch(llr[:1], L, True)
+        assert dec.last_decode_kernel() == "bp_nodes_kernel"
+        dec.close()
