@@ -30,9 +30,6 @@ struct LdsParams {
     const int* perm;       // [n]  variable handled at VN position p (thread p % nt, step p / nt)
     const int* pos_of_var; // [n]  inverse of perm
     const int* vn_off;     // [n*DV] byte offset in msg of edge k of the variable at position p, [p*DV + k]
-    const int* edge_slot;  // [E]  LDS slot of CSR edge e
-    const int* edge_pos;   // [E]  VN position of the variable of CSR edge e (its decision bit index)
-    const int* edge_col;   // [E]  variable of CSR edge e
     const float* llr;      // [frames][n] channel LLRs, or null
     const uint8_t* r;      // [frames][n] hard received words (then lambda = +-l0 / +-l1), or null
     float l0, l1;          // already in the rule's LLR unit
@@ -62,30 +59,6 @@ __device__ __forceinline__ uint32_t lds_address(const void* generic) {
 __device__ __forceinline__ float lds_load(uint32_t a) { return *(const lds_float*)(uintptr_t)a; }
 __device__ __forceinline__ void lds_store(uint32_t a, float v) { *(lds_float*)(uintptr_t)a = v; }
 
-// number of unsatisfied checks of the decisions in `bits` (sumSyndro, LogDecoder.java:108-116);
-// bits are indexed by VN position, edge_pos maps an edge to the position of its variable
-template <int DC>
-__device__ __forceinline__ int lds_syndrome(const LdsParams& p, const uint32_t* bits, int* red, int t, int nt) {
-    int cnt = 0;
-    for (int i = t; i < p.m; i += nt) {
-        uint32_t par = 0u;
-#pragma unroll
-        for (int k = 0; k < DC; ++k) {
-            const int q = p.edge_pos[(long long)i * DC + k];
-            par ^= bits[q >> 5] >> (q & 31);
-        }
-        cnt += (int)(par & 1u);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-    if ((t & 63) == 0 && cnt) atomicAdd(red, cnt);
-    __syncthreads();
-    const int total = *red;
-    __syncthreads();
-    if (t == 0) *red = 0;
-    return total;
-}
-
 // CPT (even) checks and kLdsVpt variables per thread, exactly: m = CPT * blockDim.x, n = kLdsVpt * blockDim.x.
 // WPE = wavefronts per SIMD the register budget is set for: 6 (80 registers, three 8-wave workgroups
 // per CU) or 4 (128 registers, two).
@@ -97,8 +70,6 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
     uint32_t* bits = reinterpret_cast<uint32_t*>(smem + p.E); // [nw], by VN position
     int* red = reinterpret_cast<int*>(bits + p.nw);           // syndrome accumulator
     const int t = threadIdx.x, nt = blockDim.x;
-    const long long frame = blockIdx.x;
-    if (frame >= p.frames) return;
     char* msgb = reinterpret_cast<char*>(msg);
 
     // LDS addresses of the edge slots of this thread's variables: fixed for the whole decode, and
@@ -112,8 +83,12 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
             off[v][k] = lds_address(msgb + p.vn_off[(long long)(t + v * nt) * DV + k]);
             asm volatile("" : "+v"(off[v][k]));
         }
-    // channel LLR of variable j of this frame (LogDecoder.java:49-54 for a hard received word); the
-    // frame's 16 KiB are read twice (once per edge, once per variable), the second time from cache
+    // With early termination a workgroup decodes frames blockIdx.x, blockIdx.x + gridDim.x, ... in turn:
+    // the addresses above are formed once for all of them, which counts when a frame takes a handful of
+    // iterations.  At fixed iterations it takes one frame (the launch gives it no second one), and the
+    // compiler sees a body that runs once and keeps nothing else alive across it.
+    for (long long frame = blockIdx.x; frame < p.frames; frame += gridDim.x) {
+    // channel LLR of variable j of this frame (LogDecoder.java:49-54 for a hard received word)
     const float* src_llr = p.llr ? p.llr + frame * p.n : nullptr;
     const uint8_t* src_r = p.r ? p.r + frame * p.n : nullptr;
     auto lam_of = [&](int j) -> float {
@@ -122,18 +97,14 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
         return (src_r[j] == 0) ? mag : -mag;
     };
     if (t == 0) *red = 0;
-    // Early termination keeps the syndrome itself, one bit per check, and only toggles the checks of
-    // the variables whose decision changed since the previous iteration (few, after the first ones):
-    // all decisions 0 and all syndrome bits 0 is the consistent state to start from.
+    // The syndrome is kept as one bit per check.  With early termination it is maintained every iteration
+    // by toggling the checks of the variables whose decision changed since the previous one (few, after
+    // the first iterations); at fixed iterations it is formed once at the end, from the variables decided
+    // 1.  All decisions 0 and all syndrome bits 0 is the consistent state to start from.
     uint32_t* par = reinterpret_cast<uint32_t*>(red + 4);   // [m / 32]
     const int mw = p.m >> 5;
-    if constexpr (EARLY) {
-        for (int w = t; w < mw; w += nt) par[w] = 0u;
-    }
+    for (int w = t; w < mw; w += nt) par[w] = 0u;
     uint32_t mydec = 0u;  // bit v: the current decision of this thread's variable v
-    // beta of the first iteration: lambda + the zero-initialised alpha (LogDecoder.java:57, :70-77)
-    for (int e = t; e < (int)p.E; e += nt) msg[p.edge_slot[e]] = lam_of(p.edge_col[e]) + 0.0f;
-    __syncthreads();
 
     // channel LLRs of this thread's own variables stay in registers for the whole decode
     v2f vl[kLdsVpt / 2];
@@ -143,6 +114,32 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
         asm volatile("" : "+v"(a), "+v"(b));  // loaded once, here
         vl[v / 2] = v2f{a, b};
     }
+    // beta of the first iteration: lambda + the zero-initialised alpha (LogDecoder.java:57, :70-77),
+    // written from the variable side: the slots of a variable's edges are the addresses held above
+#pragma unroll
+    for (int v = 0; v < kLdsVpt; v += 2)
+#pragma unroll
+        for (int k = 0; k < DV; ++k) {
+            lds_store(off[v][k], vl[v / 2].x + 0.0f);
+            lds_store(off[v + 1][k], vl[v / 2].y + 0.0f);
+        }
+    __syncthreads();
+
+    // toggles the syndrome bits of the checks of this thread's variable v (v compile-time after unrolling)
+    auto toggle_checks = [&](int v) {
+#pragma unroll
+        for (int vv = 0; vv < kLdsVpt; ++vv) {
+            if (vv != v) continue;
+#pragma unroll
+            for (int k = 0; k < DV; ++k) {
+                // slot -> syndrome bit: 2 * (pair row) + (which check of the pair); any fixed
+                // one-to-one numbering of the checks serves
+                const uint32_t slot = (off[vv][k] - lds_base) >> 2;
+                const uint32_t b = 2u * (slot / (2u * DC)) + (slot & 1u);
+                atomicXor(&par[b >> 5], 1u << (b & 31u));
+            }
+        }
+    };
 
     int iters = p.max_iters, synd = 0;
     bool converged = false;
@@ -196,20 +193,8 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
             uint32_t changed = newdec ^ mydec;
             mydec = newdec;
             while (changed) {  // rare after the first iterations
-                const int v = __builtin_ctz(changed);
+                toggle_checks(__builtin_ctz(changed));
                 changed &= changed - 1u;
-#pragma unroll
-                for (int vv = 0; vv < kLdsVpt; ++vv) {
-                    if (vv != v) continue;
-#pragma unroll
-                    for (int k = 0; k < DV; ++k) {
-                        // slot -> syndrome bit: 2 * (pair row) + (which check of the pair); any fixed
-                        // one-to-one numbering of the checks serves
-                        const uint32_t slot = (off[vv][k] - lds_base) >> 2;
-                        const uint32_t b = 2u * (slot / (2u * DC)) + (slot & 1u);
-                        atomicXor(&par[b >> 5], 1u << (b & 31u));
-                    }
-                }
             }
             __syncthreads();
             // "sumSyndro == 0" (LogDecoder.java:108-119): no bit set in any word
@@ -235,19 +220,22 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
         }
     }
     __syncthreads();
-    if constexpr (EARLY) {
-        if (!converged) {  // weight of the last iteration's syndrome: its bits are all in the first wave's reach
-            int cnt = (t < mw) ? __popc(par[t]) : 0;
-            if (t < 64) {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-                if (t == 0) *red = cnt;
-            }
-            __syncthreads();
-            synd = *red;
+    if constexpr (!EARLY) {  // "sumSyndro" of the last decisions (LogDecoder.java:108-116)
+        uint32_t ones = mydec;
+        while (ones) {
+            toggle_checks(__builtin_ctz(ones));
+            ones &= ones - 1u;
         }
-    } else {
-        synd = lds_syndrome<DC>(p, bits, red, t, nt);
+        __syncthreads();
+    }
+    if (!converged) {  // weight of the syndrome
+        int cnt = 0;
+        for (int w = t; w < mw; w += nt) cnt += __popc(par[w]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if ((t & 63) == 0 && cnt) atomicAdd(red, cnt);
+        __syncthreads();
+        synd = *red;
     }
 
     uint8_t* out = p.hard + frame * p.n;
@@ -268,11 +256,15 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
         if (p.out_iters) p.out_iters[frame] = iters;
         if (p.out_synd) p.out_synd[frame] = synd;
     }
+    if constexpr (!EARLY) break;
+    __syncthreads();  // the next frame reuses the LDS
+    }
 }
 
 struct LdsLaunch {
     int rule;
     bool early;
+    int frames_per_wg;  // frames one workgroup decodes in turn (>= 1; early termination only)
     int wpe;  // 4 or 6, see bp_lds_kernel
     int threads;
     size_t lds_bytes;
@@ -281,7 +273,8 @@ struct LdsLaunch {
 
 template <int DC, int DV, int CPT>
 inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
-    const dim3 grid((unsigned)p.frames), block((unsigned)l.threads);
+    const long long fpw = (l.early && l.frames_per_wg > 0) ? l.frames_per_wg : 1;
+    const dim3 grid((unsigned)((p.frames + fpw - 1) / fpw)), block((unsigned)l.threads);
 #define LDPC_LDS2(R, E, W)                                                                                   \
     do {                                                                                                     \
         auto k = bp_lds_kernel<DC, DV, R, E, CPT, W>;                                                        \

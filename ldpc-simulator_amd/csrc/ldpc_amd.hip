@@ -383,7 +383,6 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             LdsParams q{};
             q.m = c->m; q.n = n; q.nw = c->nw; q.E = c->E;
             q.perm = c->d_res; q.pos_of_var = q.perm + n; q.vn_off = q.pos_of_var + n;
-            q.edge_slot = q.vn_off + c->E; q.edge_pos = q.edge_slot + c->E; q.edge_col = c->d_edge_col;
             q.llr = src.kind == Src::Float ? src.llr : nullptr;
             q.r = src.kind == Src::Bsc ? src.r : nullptr;
             q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
@@ -394,10 +393,14 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
                      : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
             l.early = early; l.threads = nt; l.lds_bytes = lds_bytes; l.stream = s;
-            // measured: three workgroups per CU pay off only for the fixed-iteration (6,3) kernel; every
-            // other variant loses more to register spills at 80 registers than it gains in occupancy
-            l.wpe = (!early && c->reg_dc == 6) ? 6 : 4;
+            // measured: three workgroups per CU (80 registers) pay off for the (6,3) kernels; the (8,2)
+            // kernels lose more to register spills than they gain in occupancy
+            l.wpe = c->reg_dc == 6 ? 6 : 4;
             if (const char* env = getenv("LDPC_AMD_LDS_WPE")) l.wpe = atoi(env);
+            // with early termination a workgroup takes several frames in turn, once there are enough of
+            // them to keep every CU supplied with workgroups that finish at different times
+            l.frames_per_wg = early ? (int)std::max<long long>(1, std::min<long long>(8, frames / 16384)) : 1;
+            if (const char* env = getenv("LDPC_AMD_LDS_FPW")) l.frames_per_wg = std::max(1, atoi(env));
             while (c->ev.size() < 2) {
                 hipEvent_t e;
                 LDPC_HIP(c, hipEventCreate(&e));
