@@ -125,18 +125,22 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
         }
     __syncthreads();
 
-    // toggles the syndrome bits of the checks of this thread's variable v (v compile-time after unrolling)
-    auto toggle_checks = [&](int v) {
+    // toggles the syndrome bits of the checks of those of this thread's variables whose bit is set in
+    // `which` (static indices into off[][]: a run-time index would move the array to scratch memory)
+    auto toggle_checks = [&](uint32_t which) {
 #pragma unroll
-        for (int vv = 0; vv < kLdsVpt; ++vv) {
-            if (vv != v) continue;
+        for (int v = 0; v < kLdsVpt; ++v) {
+            if ((which >> v) & 1u) {
 #pragma unroll
-            for (int k = 0; k < DV; ++k) {
-                // slot -> syndrome bit: 2 * (pair row) + (which check of the pair); any fixed
-                // one-to-one numbering of the checks serves
-                const uint32_t slot = (off[vv][k] - lds_base) >> 2;
-                const uint32_t b = 2u * (slot / (2u * DC)) + (slot & 1u);
-                atomicXor(&par[b >> 5], 1u << (b & 31u));
+                for (int k = 0; k < DV; ++k) {
+                    // slot -> syndrome bit: 2 * (pair row) + (which check of the pair); any fixed
+                    // one-to-one numbering of the checks serves
+                    uint32_t o = off[v][k];
+                    asm volatile("" : "+v"(o));  // formed here, when needed: 24 more loop invariants do not fit
+                    const uint32_t slot = (o - lds_base) >> 2;
+                    const uint32_t b = 2u * (slot / (2u * DC)) + (slot & 1u);
+                    atomicXor(&par[b >> 5], 1u << (b & 31u));
+                }
             }
         }
     };
@@ -190,12 +194,9 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
             newdec |= (g.x < 0.0f ? 1u : 0u) << v | (g.y < 0.0f ? 1u : 0u) << (v + 1);
         }
         if constexpr (EARLY) {
-            uint32_t changed = newdec ^ mydec;
+            const uint32_t changed = newdec ^ mydec;
             mydec = newdec;
-            while (changed) {  // rare after the first iterations
-                toggle_checks(__builtin_ctz(changed));
-                changed &= changed - 1u;
-            }
+            if (changed) toggle_checks(changed);  // rare after the first iterations
             __syncthreads();
             // "sumSyndro == 0" (LogDecoder.java:108-119): no bit set in any word
             const int bad = __syncthreads_or(t < mw && par[t] != 0u);
@@ -221,11 +222,7 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
     }
     __syncthreads();
     if constexpr (!EARLY) {  // "sumSyndro" of the last decisions (LogDecoder.java:108-116)
-        uint32_t ones = mydec;
-        while (ones) {
-            toggle_checks(__builtin_ctz(ones));
-            ones &= ones - 1u;
-        }
+        toggle_checks(mydec);
         __syncthreads();
     }
     if (!converged) {  // weight of the syndrome
