@@ -1072,43 +1072,64 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
     long long chunk = (long long)((2048ull << 20) / (n * (in_elem + 1) + 8));
     chunk = std::max<long long>(256, std::min<long long>(chunk, 1ll << 20));
     chunk = std::min<long long>(chunk, std::max<long long>(frames, 1));
-    for (long long f0 = 0; f0 < frames; f0 += chunk) {
+    // Chunks alternate between two sets of buffers on two streams: the channel generation of chunk i + 1
+    // and the error accounting of chunk i - 1 (HBM-bound, no LDS) run in the wave slots the resident
+    // decode kernel of chunk i (VALU-bound, all of the LDS) leaves free.  Engines that keep their
+    // messages in the context's one workspace must not overlap: they stay on one stream and one set.
+    for (int i = 0; i < 2; ++i)
+        if (!c->io_stream[i]) LDPC_HIP(c, hipStreamCreateWithFlags(&c->io_stream[i], hipStreamNonBlocking));
+    LDPC_HIP(c, hipStreamSynchronize(nullptr));  // the counters are zero before the other streams add to them
+    bool overlap = false;
+    long long index = 0;
+    for (long long f0 = 0; f0 < frames; f0 += chunk, ++index) {
         const long long nf = std::min<long long>(chunk, frames - f0);
-        if (int rc = ensure_stage(c, 0, (size_t)nf * n * in_elem)) return rc;
-        if (int rc = ensure_stage(c, 1, (size_t)nf * n)) return rc;
-        if (int rc = ensure_stage(c, 2, (size_t)nf * 4)) return rc;
-        if (int rc = ensure_stage(c, 3, (size_t)nf * 4)) return rc;
+        const int set = overlap ? (int)(index & 1) : 0;
+        hipStream_t s = c->io_stream[set];
+        void** st = c->stage + 4 * set;
+        if (int rc = ensure_stage(c, 4 * set + 0, (size_t)nf * n * in_elem)) return rc;
+        if (int rc = ensure_stage(c, 4 * set + 1, (size_t)nf * n)) return rc;
+        if (int rc = ensure_stage(c, 4 * set + 2, (size_t)nf * 4)) return rc;
+        if (int rc = ensure_stage(c, 4 * set + 3, (size_t)nf * 4)) return rc;
         int rc;
         const uint8_t* cw = nullptr;  // transmitted words of this chunk; null = the all-zero word
         if (c->d_gen) {
-            if (c->stage_cw_bytes < (size_t)nf * n) {
+            if (c->stage_cw_bytes < (size_t)2 * chunk * n) {
+                LDPC_HIP(c, hipStreamSynchronize(c->io_stream[0]));
+                LDPC_HIP(c, hipStreamSynchronize(c->io_stream[1]));
                 if (c->stage_cw) LDPC_HIP(c, hipFree(c->stage_cw));
                 c->stage_cw = nullptr;
                 c->stage_cw_bytes = 0;
-                LDPC_HIP(c, hipMalloc(&c->stage_cw, (size_t)nf * n));
-                c->stage_cw_bytes = (size_t)nf * n;
+                LDPC_HIP(c, hipMalloc(&c->stage_cw, (size_t)2 * chunk * n));
+                c->stage_cw_bytes = (size_t)2 * chunk * n;
             }
-            rc = gen_codewords(c, seed, first_frame + f0, nf, (uint8_t*)c->stage_cw, nullptr);
+            uint8_t* mine = (uint8_t*)c->stage_cw + (size_t)set * chunk * n;
+            rc = gen_codewords(c, seed, first_frame + f0, nf, mine, s);
             if (rc) return rc;
-            cw = (const uint8_t*)c->stage_cw;
+            cw = mine;
         }
         SrcArgs src{};
         if (awgn) {
-            rc = gen_awgn(c, param, seed, first_frame + f0, nf, cw, (float*)c->stage[0], nullptr);
-            src = SrcArgs{Src::Float, (const float*)c->stage[0], nullptr, 0.0, 0.0};
+            rc = gen_awgn(c, param, seed, first_frame + f0, nf, cw, (float*)st[0], s);
+            src = SrcArgs{Src::Float, (const float*)st[0], nullptr, 0.0, 0.0};
         } else {
-            rc = gen_bsc(c, channel, param, seed, first_frame + f0, nf, cw, (uint8_t*)c->stage[0], nullptr);
-            src = SrcArgs{Src::Bsc, nullptr, (const uint8_t*)c->stage[0], l0, l1};
+            rc = gen_bsc(c, channel, param, seed, first_frame + f0, nf, cw, (uint8_t*)st[0], s);
+            src = SrcArgs{Src::Bsc, nullptr, (const uint8_t*)st[0], l0, l1};
         }
         if (rc) return rc;
-        rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)c->stage[1], (int32_t*)c->stage[2],
-                        (int32_t*)c->stage[3], nullptr);
+        rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)st[1], (int32_t*)st[2], (int32_t*)st[3], s);
         if (rc) return rc;
-        rc = count_launch(c, nf, (const uint8_t*)c->stage[1], cw, awgn ? nullptr : (const uint8_t*)c->stage[0],
-                          awgn ? (const float*)c->stage[0] : nullptr, (const int32_t*)c->stage[2],
-                          (const int32_t*)c->stage[3], max_iters, c->d_counters, nullptr);
+        rc = count_launch(c, nf, (const uint8_t*)st[1], cw, awgn ? nullptr : (const uint8_t*)st[0],
+                          awgn ? (const float*)st[0] : nullptr, (const int32_t*)st[2], (const int32_t*)st[3], max_iters,
+                          c->d_counters, s);
         if (rc) return rc;
+        if (index == 0) {
+            const char* k = c->last_kernel;
+            overlap = k && (!strcmp(k, "bp_lds_kernel") || !strcmp(k, "bp_lds_gen_kernel"));
+            if (const char* env = getenv("LDPC_AMD_SIM_OVERLAP")) overlap = overlap && atoi(env) != 0;
+        }
     }
+    LDPC_HIP(c, hipStreamSynchronize(c->io_stream[0]));
+    LDPC_HIP(c, hipStreamSynchronize(c->io_stream[1]));
     std::vector<unsigned long long> h(nc);
     LDPC_HIP(c, hipMemcpy(h.data(), c->d_counters, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < nc; ++i) counters[i] += h[i];
