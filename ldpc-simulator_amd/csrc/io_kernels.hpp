@@ -191,9 +191,32 @@ __global__ void __launch_bounds__(256) gen_codewords_kernel(int n, int nw, int k
 // ---- error accounting (LDPC_GallagerIntStreamSimu.java:136-183, c = all-zero) -------------------------
 // One wave per frame at a time, lanes stride the positions; a block handles 64 frames and keeps its
 // sums in LDS so that each block issues at most (16 + max_iters) global atomics.
-struct RxNone { __device__ int operator()(long long) const { return 0; } };
-struct RxBytes { const uint8_t* p; __device__ int operator()(long long i) const { return p[i] != 0; } };
-struct RxLlrSign { const float* p; __device__ int operator()(long long i) const { return p[i] < 0.0f; } };
+// rx(i): received hard bit at position i of the batch; four(i): the bits at i .. i+3 in bits 0, 8, 16, 24
+// (i a multiple of 4, rows 4-byte aligned)
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) {  // 0x01 in every byte of w that is not zero
+    return (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) >> 7 & 0x01010101u;
+}
+struct RxNone {
+    __device__ int operator()(long long) const { return 0; }
+    __device__ uint32_t four(long long) const { return 0u; }
+    __device__ bool aligned() const { return true; }
+};
+struct RxBytes {
+    const uint8_t* p;
+    __device__ int operator()(long long i) const { return p[i] != 0; }
+    __device__ uint32_t four(long long i) const { return nonzero_bytes(*reinterpret_cast<const uint32_t*>(p + i)); }
+    __device__ bool aligned() const { return ((uintptr_t)p & 3) == 0; }
+};
+struct RxLlrSign {
+    const float* p;
+    __device__ int operator()(long long i) const { return p[i] < 0.0f; }
+    __device__ uint32_t four(long long i) const {
+        const float4 v = *reinterpret_cast<const float4*>(p + i);
+        return (v.x < 0.0f ? 1u : 0u) | (v.y < 0.0f ? 0x100u : 0u) | (v.z < 0.0f ? 0x10000u : 0u) |
+               (v.w < 0.0f ? 0x1000000u : 0u);
+    }
+    __device__ bool aligned() const { return ((uintptr_t)p & 15) == 0; }
+};
 
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 #pragma unroll
@@ -212,11 +235,30 @@ __global__ void __launch_bounds__(256) count_errors_kernel(int n, int k_info, lo
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long fb = (long long)blockIdx.x * 64;
+    const bool vec = (n & 3) == 0 && (((uintptr_t)hard | (uintptr_t)cw) & 3) == 0 && (!HAS_RX || rx.aligned());
     for (int q = wave; q < 64; q += 4) {
         const long long f = fb + q;
         if (f >= frames) break;
         unsigned info = 0, chk = 0, mis = 0, ch = 0;
         const uint8_t* d = hard + f * n;
+        if (vec) {  // four positions per lane and step: one 4-byte (16-byte for LLRs) load each
+            for (int j = 4 * lane; j < n; j += 256) {
+                const uint32_t c4 = cw ? nonzero_bytes(*reinterpret_cast<const uint32_t*>(cw + f * n + j)) : 0u;
+                const uint32_t d4 = nonzero_bytes(*reinterpret_cast<const uint32_t*>(d + j)) ^ c4;
+                // bytes of positions below k_info
+                const int left = k_info - j;
+                const uint32_t im = left >= 4 ? 0x01010101u : left <= 0 ? 0u : (0x01010101u >> (8 * (4 - left)));
+                info += __popc(d4 & im);
+                chk += __popc(d4 & ~im);
+                if (HAS_RX) {
+                    if (left > 0) {
+                        const uint32_t r4 = (rx.four(f * n + j) ^ c4) & im;
+                        ch += __popc(r4);
+                        mis += __popc(d4 & im & ~r4);
+                    }
+                }
+            }
+        } else
         for (int j = lane; j < n; j += 64) {
             const unsigned cj = cw ? (cw[f * n + j] != 0) : 0u;  // transmitted bit; null = all-zero word
             const unsigned dj = (unsigned)(d[j] != 0) ^ cj;       // decoded bit differs from it

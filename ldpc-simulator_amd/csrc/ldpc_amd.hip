@@ -540,12 +540,17 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
                 c->ev.push_back(e);
             }
             LDPC_HIP(c, hipEventRecord(c->ev[0], s));
-            LDPC_HIP(c, bp_nodes_launch(l, q));
-            LDPC_HIP(c, hipEventRecord(c->ev[1], s));
-            c->timed_launches = 1;
-            c->timed_frames = frames;
-            c->last_kernel = "bp_nodes_kernel";
-            return LDPC_AMD_OK;
+            if (bp_nodes_launch(l, q) == hipSuccess) {
+                LDPC_HIP(c, hipEventRecord(c->ev[1], s));
+                c->timed_launches = 1;
+                c->timed_frames = frames;
+                c->last_kernel = "bp_nodes_kernel";
+                return LDPC_AMD_OK;
+            }
+            // the runtime would not start the grid as a whole (nothing has run): this context leaves the
+            // engine alone from now on, and the batch goes through the sweep launches below
+            (void)hipGetLastError();
+            c->nodes_blocks = -1;
         }
     }
     const int maxdeg = std::max(c->max_dc, c->max_dv);

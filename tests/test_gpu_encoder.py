@@ -104,3 +104,30 @@ def test_simulate_with_generator(sys_code, oracle):
     want = g.simulate(oracle.CH_AWGN, 3.5, seed=3, first_frame=0, frames=3000, max_iters=40, G=c["eg"])
     assert abs(int(rand[10]) - int(want[10])) <= 2 and abs(int(rand[1]) - int(want[1])) <= 2, (rand[:12], want[:12])
     dec.set_generator(None)
+
+
+def test_count_errors_word_and_byte_paths(pkg, oracle):
+    """The accounting kernel reads four positions per lane when n is a multiple of 4 (also across the
+    information/check boundary) and one otherwise."""
+    import torch
+    rng = np.random.default_rng(4)
+    for n, m in ((24, 9), (24, 12), (22, 9), (256, 95)):
+        H = (rng.random((m, n)) < 0.2).astype(np.uint8)
+        H[np.arange(m), rng.integers(0, n, m)] = 1
+        rows, cols = np.nonzero(H)
+        dec = pkg.Decoder(m, n, rows.astype(np.int32), cols.astype(np.int32))
+        F, L = 333, 12
+        hard = (rng.random((F, n)) < 0.3).astype(np.uint8)
+        rx = (rng.random((F, n)) < 0.3).astype(np.uint8)
+        cw = (rng.random((F, n)) < 0.5).astype(np.uint8)
+        it = rng.integers(1, L + 1, F).astype(np.int32)
+        sw = (rng.random(F) < 0.5).astype(np.int32) * rng.integers(1, 5, F).astype(np.int32)
+        d = {k: torch.from_numpy(v).cuda() for k, v in (("hard", hard), ("rx", rx), ("cw", cw), ("it", it), ("sw", sw))}
+        for use_cw in (False, True):
+            d_cnt = torch.zeros(16 + L, dtype=torch.int64, device="cuda")
+            dec.count_errors_dev(F, d["hard"].data_ptr(), d["rx"].data_ptr(), d["it"].data_ptr(), d["sw"].data_ptr(), L,
+                                 d_cnt.data_ptr(), d_cw=d["cw"].data_ptr() if use_cw else 0)
+            torch.cuda.synchronize()
+            want = oracle.count_errors(m, n, hard, rx, it, sw, L, cw=cw if use_cw else None)
+            assert (d_cnt.cpu().numpy().astype(np.uint64) == want).all(), (n, m, use_cw)
+        dec.close()
