@@ -122,7 +122,21 @@ __global__ void __launch_bounds__(256, 4) rows_synd_kernel(RowsParams p) {
         uint32_t par[FPL];
 #pragma unroll
         for (int f = 0; f < FPL; ++f) par[f] = 0u;
-        for (int e = e0; e < e1; ++e) {
+        int e = e0;
+        for (; e + 4 <= e1; e += 4) {  // four loads in flight: the row is a chain of cache hits otherwise
+            int j[4];
+            uint32_t v[4][FPL];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                j[u] = p.b.edge_col[e + u];
+                ldw<FPL>(bits + (long long)(j[u] >> 5) * p.b.bits_row, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int f = 0; f < FPL; ++f) par[f] ^= v[u][f] >> (j[u] & 31);
+        }
+        for (; e < e1; ++e) {
             const int j = p.b.edge_col[e];
             uint32_t v[FPL];
             ldw<FPL>(bits + (long long)(j >> 5) * p.b.bits_row, v);
