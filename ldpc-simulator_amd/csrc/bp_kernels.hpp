@@ -119,6 +119,7 @@ __device__ __forceinline__ void stw(uint32_t* p, const uint32_t (&v)[FPL]) {
 // +-Inf give +-1 exactly and NaN stays NaN, as Math.tanh does.  Below |b| = 0.25 the
 // quotient cancels, so the odd Taylor polynomial is used there (error < 2e-9 relative).
 __device__ __forceinline__ float tanh_half(float b) {
+#pragma clang fp contract(off)  // fused operations only where written: every engine must round alike
     const float e = __builtin_amdgcn_exp2f(b * 1.4426950408889634f);
     const float r = __builtin_amdgcn_rcpf(e + 1.0f);
     const float big = fmaf(-2.0f, r, 1.0f);
@@ -132,6 +133,7 @@ __device__ __forceinline__ float tanh_half(float b) {
 // (2/0 and ln 0), NaN stays NaN.  Below |p| = 0.15 the logarithm cancels, so the series
 // 2(p + p^3/3 + ... + p^9/9) is used there.
 __device__ __forceinline__ float atanh2(float p) {
+#pragma clang fp contract(off)  // 1 + p must not fuse with the product the caller formed p from
     const float q = (1.0f + p) * __builtin_amdgcn_rcpf(1.0f - p);
     const float big = __builtin_amdgcn_logf(q) * 0.6931471805599453f;
     const float p2 = p * p;
