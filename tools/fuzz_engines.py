@@ -36,11 +36,11 @@ def random_code(rng):
     return m, n, rows.astype(np.int32), cols.astype(np.int32)
 
 
-def run(dec, llr, iters, early, env):
+def run(dec, call, env):
     for k in KEYS:
         os.environ.pop(k, None)
     os.environ.update(env)
-    out = dec.decode_batch(llr, iters, early)
+    out = call()
     kernel = dec.last_decode_kernel()
     for k in KEYS:
         os.environ.pop(k, None)
@@ -71,11 +71,18 @@ def main():
             llr[rng.integers(0, F), rng.integers(0, n)] = np.inf
         if rng.random() < 0.1:
             llr[rng.integers(0, F), rng.integers(0, n)] = 0.0
-        ref, _ = run(dec, llr, iters, early, {"LDPC_AMD_ENGINE": "stream", "LDPC_AMD_ROWS": "1"})
+        if rng.random() < 0.3:  # hard received words, the reference's own input (LogDecoder.java:45-54)
+            r = (rng.random((F, n)) < 0.04).astype(np.uint8)
+            e = float(rng.uniform(0.005, 0.08))
+            mode = int(rng.integers(0, 3))
+            call = lambda: dec.decode_bsc_batch(r, e, iters, mode, early)
+        else:
+            call = lambda: dec.decode_batch(llr, iters, early)
+        ref, _ = run(dec, call, {"LDPC_AMD_ENGINE": "stream", "LDPC_AMD_ROWS": "1"})
         for name, env in (("default", {}), ("generic", {"LDPC_AMD_ENGINE": "generic"}),
                           ("one-launch", {"LDPC_AMD_ENGINE": "stream", "LDPC_AMD_ROWS": "0"}),
                           ("nodes", {"LDPC_AMD_GENERIC_LDS_KB": "0", "LDPC_AMD_ENGINE": "generic", "LDPC_AMD_NODES": "1"})):
-            out, kernel = run(dec, llr, iters, early, env)
+            out, kernel = run(dec, call, env)
             seen[kernel] = seen.get(kernel, 0) + 1
             same = all(bool((a == b).all()) for a, b in zip(out, ref))
             if not same:
