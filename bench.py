@@ -255,7 +255,7 @@ def main():
             "kernel": kernel,
             "note": ("frame-resident kernel: messages stay in LDS, so `achieved` (algorithmic message bytes / time) "
                      "exceeds what HBM could deliver and `traffic` (measured HBM bytes) is far below it; the kernel is "
-                     "bound by VALU issue, see DESIGN.md" if kernel == "bp_lds_kernel" else
+                     "bound by VALU issue (see the issue field)" if kernel == "bp_lds_kernel" else
                      "frame-major streaming kernel: HBM-bound"),
             "launch_ms": launch_s * 1e3,
             "algorithmic_bytes_per_launch": frames_per_launch * b_frame,
