@@ -47,9 +47,9 @@ def run(dec, call, env):
     return out, kernel
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+def fuzz(cases, seed):
+    """Runs the cases; returns ({kernel name: decodes}, number of mismatching decodes)."""
+    rng = np.random.default_rng(seed)
     bad = 0
     seen = {}
     for c in range(cases):
@@ -96,8 +96,11 @@ def main():
                 print("MISMATCH case %d %s (%s): m=%d n=%d E=%d dc<=%d dv<=%d rule=%d F=%d iters=%d early=%d" % (
                     c, name, kernel, m, n, len(rows), dec.max_dc, dec.max_dv, rule, F, iters, early), flush=True)
         dec.close()
-    print("cases %d, kernels seen %s, mismatches %d" % (cases, seen, bad))
-    sys.exit(1 if bad else 0)
+    return seen, bad
 
 
-main()
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    kernels, mismatches = fuzz(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print("cases %d, kernels seen %s, mismatches %d" % (n_cases, kernels, mismatches))
+    sys.exit(1 if mismatches else 0)
