@@ -198,8 +198,11 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
             mydec = newdec;
             if (changed) toggle_checks(changed);  // rare after the first iterations
             __syncthreads();
-            // "sumSyndro == 0" (LogDecoder.java:108-119): no bit set in any word
-            const int bad = __syncthreads_or(t < mw && par[t] != 0u);
+            // "sumSyndro == 0" (LogDecoder.java:108-119): no bit set in any word.  Every wave scans all the
+            // words for itself, so all reach the same verdict without a reduction or a second barrier (the
+            // next toggles come after the barrier that ends the next check-node phase).
+            const uint32_t any = ((t & 63) < mw) ? par[t & 63] : 0u;  // m <= 2048 here: at most 64 words
+            const bool bad = __ballot(any != 0u) != 0ull;
             if (!bad) {
                 iters = it + 1;
                 converged = true;

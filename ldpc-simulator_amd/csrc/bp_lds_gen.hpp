@@ -229,9 +229,11 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
         mydec = newdec;
         __syncthreads();
         if constexpr (EARLY) {
+            // every wave scans all the words for itself: the same verdict everywhere without a reduction or
+            // a second barrier (the next toggles come after the barrier that ends the next check-node phase)
             uint32_t any = 0u;
-            for (int w = t; w < mw; w += nt) any |= par[w];
-            if (!__syncthreads_or(any != 0u)) {  // "sumSyndro == 0", LogDecoder.java:108-119
+            for (int w = lane; w < mw; w += 64) any |= par[w];
+            if (__ballot(any != 0u) == 0ull) {  // "sumSyndro == 0", LogDecoder.java:108-119
                 iters = it + 1;
                 converged = true;
                 break;

@@ -374,7 +374,8 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         const int nt = n / kLdsVpt;
         // messages | packed decisions | accumulator | one syndrome bit per check
         const size_t lds_bytes = ((size_t)c->E + (size_t)c->nw + 4 + (size_t)(c->m + 31) / 32) * sizeof(float);
-        bool use = shape && n % (kLdsVpt * 64) == 0 && nt <= 512 && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll;
+        bool use = shape && n % (kLdsVpt * 64) == 0 && nt <= 512 && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll &&
+                   c->m <= 2048;  // the convergence test reads the syndrome words with one wavefront
         if (const char* env = getenv("LDPC_AMD_ENGINE")) {
             if (!strcmp(env, "stream") || !strcmp(env, "generic")) use = false;
         }
