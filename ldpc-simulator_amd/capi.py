@@ -28,6 +28,8 @@ _vp, _i32, _i64, _u64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_
 SIGNATURES = {
     "ldpc_amd_version": (C.c_int, []),
     "ldpc_amd_last_error": (C.c_char_p, [_vp]),
+    "ldpc_amd_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(_vp)]),
+    "ldpc_amd_host_free": (C.c_int, [_vp]),
     "ldpc_amd_create": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _i32, C.POINTER(_vp)]),
     "ldpc_amd_destroy": (C.c_int, [_vp]),
     "ldpc_amd_info": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
@@ -100,6 +102,42 @@ class LdpcError(RuntimeError):
 
 def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class HostBuffer:
+    """Page-locked host memory from ldpc_amd_host_alloc, viewed as a NumPy array: the host-buffer entry
+    points copy from and to it at link speed.  close() (or the context manager) releases it; views taken
+    from `.array` must not be used afterwards."""
+
+    def __init__(self, shape, dtype):
+        lib = load_library()
+        self.array = None
+        self._ptr = _vp()
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        rc = lib.ldpc_amd_host_alloc(max(nbytes, 1), C.byref(self._ptr))
+        if rc:
+            raise LdpcError(rc, (lib.ldpc_amd_last_error(None) or b"").decode())
+        raw = (C.c_char * max(nbytes, 1)).from_address(self._ptr.value)
+        self.array = np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self._ptr is not None and self._ptr.value:
+            self.array = None
+            load_library().ldpc_amd_host_free(self._ptr)
+            self._ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Decoder:

@@ -1142,6 +1142,29 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
     return LDPC_AMD_OK;
 }
 
+int ldpc_amd_host_alloc(uint64_t bytes, void** out) {
+    if (!out || !bytes) return fail(nullptr, LDPC_AMD_EINVAL, "host_alloc: null result pointer or empty size");
+    *out = nullptr;
+    const hipError_t e = hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return fail(nullptr, e == hipErrorOutOfMemory ? LDPC_AMD_ENOMEM : LDPC_AMD_EHIP,
+                    std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_host_free(void* ptr) {
+    if (!ptr) return LDPC_AMD_OK;
+    const hipError_t e = hipHostFree(ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, LDPC_AMD_EHIP, std::string("hipHostFree: ") + hipGetErrorString(e));
+    }
+    return LDPC_AMD_OK;
+}
+
 const char* ldpc_amd_last_decode_kernel(const ldpc_amd_ctx* c) { return c ? c->last_kernel : ""; }
 
 int ldpc_amd_last_decode_timing(ldpc_amd_ctx* c, int32_t* launches, double* kernel_ms, int64_t* frames) {

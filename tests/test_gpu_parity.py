@@ -404,3 +404,17 @@ def test_hard_decision_agreement_at_scale(c1, c2, oracle, engine):
           "gpu iters, oracle iters, oracle failure rate): %s" % (total, hard_bad, triple_bad, notes))
     assert hard_bad <= total * 1e-4, notes
     assert triple_bad <= total * 5e-4, notes
+
+
+def test_page_locked_caller_buffers(pkg, c1, oracle, engine):
+    """ldpc_amd_host_alloc: the same results from page-locked caller buffers."""
+    if engine != "resident":
+        pytest.skip("runs once")
+    m, n = c1["m"], c1["n"]
+    r = oracle.gen_bsc(m, n, oracle.CH_BSC_INFO, 0.03, seed=5, first_frame=0, frames=3000)
+    want = c1["dec"].decode_bsc_batch(r, 0.03, 50)
+    with pkg.capi.HostBuffer(r.shape, np.uint8) as buf:
+        buf.array[:] = r
+        got = c1["dec"].decode_bsc_batch(buf.array, 0.03, 50)
+    for x, y in zip(got, want):
+        assert (x == y).all()
