@@ -54,7 +54,7 @@ struct ldpc_amd_ctx {
     size_t stage_cw_bytes = 0;
     // tables of the frame-resident engine (built on first use, see build_resident_tables)
     int res_nt = 0;
-    int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E] | edge_slot[E] | edge_pos[E]
+    int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E]
     double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
     // tables of the generic frame-resident engine: cn_desc | vn_desc | pos_of_var[n] | edge_pos[E] | edge_slot[E] | col_slot[E] | col_check[E]
     int gen_nt = 0, gen_cn_steps = 0, gen_vn_steps = 0, gen_slots = 0;
@@ -212,20 +212,16 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt) {
         }
     }
     c->res_conflict = mult_cnt ? (double)mult_sum / (double)mult_cnt : 1.0;
-    std::vector<int> tab((size_t)(2 * n) + (size_t)(3 * E));
+    // layout: perm[n] (variable at each position) | pos[n] (position of each variable) | vn_off[E] (byte
+    // offsets of the edge slots of the variable at each position)
+    std::vector<int> tab((size_t)(2 * n) + (size_t)E);
     int* t_perm = tab.data();
     int* t_pos = t_perm + n;
     int* t_vn = t_pos + n;
-    int* t_slot = t_vn + E;
-    int* t_epos = t_slot + E;
     for (int p = 0; p < n; ++p) {
         t_perm[p] = perm[(size_t)p];
         t_pos[p] = pos[(size_t)p];
         for (int k = 0; k < dv; ++k) t_vn[(size_t)p * dv + k] = 4 * slot[(size_t)c->h_col_edge[(size_t)perm[(size_t)p] * dv + k]];
-    }
-    for (long long e = 0; e < E; ++e) {
-        t_slot[e] = slot[(size_t)e];
-        t_epos[e] = pos[(size_t)c->h_edge_col[(size_t)e]];
     }
     if (c->d_res) {
         LDPC_HIP(c, hipFree(c->d_res));
