@@ -168,11 +168,11 @@ def main():
 
     import ldpc_simulator_amd as L
 
-    if args.engine == "stream":
-        os.environ["LDPC_AMD_ENGINE"] = "stream"
     code = L.codes.regular_ldpc(args.n, 3, 6, seed=1)
     m, n, rows, cols = code
     dec = L.Decoder(m, n, rows, cols, device=local_rank)
+    if args.engine == "stream":
+        dec.set_option("engine", "stream")
     F, iters = args.frames, args.iters
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -265,8 +265,8 @@ def main():
     }
     if world == 1 and kernel == "bp_lds_kernel" and not args.no_stream_leg:
         # the same batch once through the frame-major HBM streaming engine, for the HBM roofline figure
-        os.environ["LDPC_AMD_ENGINE"] = "stream"
-        os.environ["LDPC_AMD_ROWS"] = "0"  # the one-launch streaming kernel: one launch = one profiler row
+        dec.set_option("engine", "stream")
+        dec.set_option("stream_kernel", 1)  # the one-launch streaming kernel: one launch = one profiler row
         for timed in (False, True):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -274,8 +274,8 @@ def main():
             nl, ms, _ = dec.last_decode_timing()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-        os.environ.pop("LDPC_AMD_ENGINE", None)
-        os.environ.pop("LDPC_AMD_ROWS", None)
+        dec.set_option("engine", "auto")
+        dec.set_option("stream_kernel", 0)
         out["streaming_engine"] = {
             "value": F * k / (t2 - t1) / 1e9, "unit": "Gbit/s", "ms_per_step": (t2 - t1) * 1e3,
             "roofline": {"bound": "hbm", "achieved": F * b_frame / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

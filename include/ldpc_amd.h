@@ -16,7 +16,11 @@
  *     distinct contexts (one per GPU / per thread) are independent.
  *   - "host" entry points take host pointers and stage through the device;
  *     "_dev" entry points take device pointers on the context's GPU plus a hipStream_t
- *     (passed as void*, NULL = default stream) and never synchronise the host.
+ *     (passed as void*, NULL = default stream) and only enqueue work on that stream.  The first
+ *     decode of a context (and any later one that needs a larger workspace or other tables)
+ *     allocates device memory with hipMalloc, which may wait for the device.
+ *   - device buffers passed to "_dev" entry points must be 16-byte aligned (every hipMalloc'd base
+ *     is): rows are read and written with 16-byte accesses when n is a multiple of 4.
  *   - per-frame outputs follow DecodeResult: hard[f][j] in {0,1}
  *     (estimatedCode, LogDecoder.java:104), iters[f] = l+1 at the first zero syndrome or
  *     max_iters (LogDecoder.java:118, :122), syndrome_weight[f] = number of unsatisfied
@@ -31,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LDPC_AMD_VERSION 100 /* 0.1.0 */
+#define LDPC_AMD_VERSION 110 /* 0.1.10 */
 
 /* error codes */
 #define LDPC_AMD_OK 0
@@ -110,6 +114,49 @@ int ldpc_amd_set_cn_rule(ldpc_amd_ctx* ctx, int32_t cn_rule);
 
 /* Cap on the bytes of device workspace a decode may hold (0 = default: 60 % of free HBM). */
 int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
+
+/*
+ * Per-context options.  Nothing in the library reads the process environment while decoding
+ * (LDPC_AMD_VERBOSE alone is read once, by ldpc_amd_create, as the initial value of
+ * LDPC_AMD_OPT_VERBOSE); which kernels run is a property of the context.  All engines return
+ * identical bits; the options choose between them for measurements and tests.  The reference has
+ * one decoder body (LogDecoder.java:64-120) and no counterpart of these.
+ */
+#define LDPC_AMD_OPT_ENGINE 1        /* LDPC_AMD_ENGINE_* below (default AUTO) */
+#define LDPC_AMD_OPT_STREAM_KERNEL 2 /* streaming engine: 0 = one launch per sweep over (tile, row chunk)
+                                        pairs (default), 1 = one launch per decode, a wavefront per tile */
+#define LDPC_AMD_OPT_NODES 3         /* node-parallel kernel for batches of at most 32 frames: -1 = by its
+                                        cost model (default), 0 = never, 1 = whenever the code allows */
+#define LDPC_AMD_OPT_SIM_OVERLAP 4   /* ldpc_amd_simulate: chunks alternate between two streams (default 1) */
+#define LDPC_AMD_OPT_VERBOSE 5       /* diagnostics on stderr */
+/* tuning knobs for measurements; 0 = the library's own choice */
+#define LDPC_AMD_OPT_TUNE_LDS_WPE 100        /* frame-resident kernels: wavefronts per SIMD compiled for (4 or 6) */
+#define LDPC_AMD_OPT_TUNE_LDS_FPW 101        /* ... frames one workgroup decodes in turn (early termination) */
+#define LDPC_AMD_OPT_TUNE_GENERIC_LDS_KB 102 /* generic frame-resident kernel: LDS it may take, KiB (-1 = none) */
+#define LDPC_AMD_OPT_TUNE_NODES_BLOCKS 103   /* node-parallel kernel: cap on its grid (never above what is resident) */
+#define LDPC_AMD_OPT_TUNE_FPL 104            /* one-launch streaming kernel: frames per lane (1, 2, 4) */
+#define LDPC_AMD_OPT_TUNE_LAYOUT 105         /* streaming arrays: 1 = [row][tile][T] instead of [tile][row][T] */
+#define LDPC_AMD_OPT_TUNE_ROWS_WAVES 106     /* sweep launches: wavefronts per launch */
+#define LDPC_AMD_OPT_TUNE_WPS 107            /* one-launch streaming kernel: wavefronts per SIMD (2 or 4) */
+#define LDPC_AMD_OPT_TUNE_NOPIPE 108         /* one-launch streaming kernel: 1 = no software pipelining */
+#define LDPC_AMD_OPT_TEST_NODES_OVERSIZE 190 /* tests: ask for a cooperative grid the runtime must refuse */
+/* read-only */
+#define LDPC_AMD_OPT_NODES_REFUSALS 200      /* cooperative launches the runtime refused on this context */
+#define LDPC_AMD_OPT_NODES_LAST_HIP_ERROR 201 /* hipError_t of the last refusal (0 = none) */
+
+#define LDPC_AMD_ENGINE_AUTO 0    /* frame-resident kernels where the code fits in LDS, else streaming */
+#define LDPC_AMD_ENGINE_GENERIC 1 /* as AUTO, but never the kernels specialised for (6,3) / (8,2) codes */
+#define LDPC_AMD_ENGINE_STREAM 2  /* frame-major streaming through HBM for every code */
+
+int ldpc_amd_set_option(ldpc_amd_ctx* ctx, int32_t key, int64_t value);
+int ldpc_amd_get_option(const ldpc_amd_ctx* ctx, int32_t key, int64_t* value);
+
+/*
+ * Text of the last event on `ctx` that did not fail the call but that a caller should know of (e.g. the
+ * runtime refused the node-parallel kernel's cooperative launch and the batch went through the sweep
+ * launches instead); "" when there has been none.
+ */
+const char* ldpc_amd_last_warning(const ldpc_amd_ctx* ctx);
 
 /*
  * Decode `frames` frames from channel LLRs (lambda_j > 0 <=> bit 0, LogDecoder.java:50).
@@ -222,10 +269,8 @@ int ldpc_amd_last_decode_timing(ldpc_amd_ctx* ctx, int32_t* launches, double* ke
  * streaming through HBM, for any code: "bp_nodes_kernel" (a batch of a few frames: one cooperative
  * launch, one thread per node), "rows_cn_kernel" (one launch per sweep; for the timing call
  * above, one "launch" is then the whole sequence of sweeps of a round) and "bp_decode_kernel" (all
- * iterations in one launch).  Environment: LDPC_AMD_ENGINE=stream turns the resident engines off,
- * LDPC_AMD_ENGINE=generic the specialised one; LDPC_AMD_ROWS=0 selects the one-launch streaming
- * kernel, LDPC_AMD_NODES=0 / 1 turns the node-parallel kernel off / on for every batch of at most 32
- * frames.  All of them return identical bits.
+ * iterations in one launch).  ldpc_amd_set_option chooses between them (LDPC_AMD_OPT_ENGINE,
+ * LDPC_AMD_OPT_STREAM_KERNEL, LDPC_AMD_OPT_NODES).  All of them return identical bits.
  */
 const char* ldpc_amd_last_decode_kernel(const ldpc_amd_ctx* ctx);
 

@@ -22,6 +22,34 @@ CNT_FRAMES, CNT_FRAME_ERRORS, CNT_INFO_BIT_ERRORS, CNT_CHECK_BIT_ERRORS = 0, 1, 
 CNT_INFO_FRAME_ERRORS, CNT_CHECK_FRAME_ERRORS, CNT_UNDETECTED, CNT_MISCORRECTED = 4, 5, 6, 7
 CNT_ITERS_CORRECT, CNT_ITERS_WRONG, CNT_CHANNEL_ERRORS, CNT_CHANNEL_ERRORS_SQ = 8, 9, 10, 11
 CNT_FIXED = 16
+# option keys of ldpc_amd_set_option / ldpc_amd_get_option (include/ldpc_amd.h)
+OPT = {
+    "engine": 1, "stream_kernel": 2, "nodes": 3, "sim_overlap": 4, "verbose": 5,
+    "lds_wpe": 100, "lds_fpw": 101, "generic_lds_kb": 102, "nodes_blocks": 103, "fpl": 104, "layout": 105,
+    "rows_waves": 106, "wps": 107, "nopipe": 108, "test_nodes_oversize": 190,
+    "nodes_refusals": 200, "nodes_last_hip_error": 201,
+}
+OPT_READ_ONLY = ("nodes_refusals", "nodes_last_hip_error")
+OPT_LIBRARY_DEFAULT = {"nodes": -1, "sim_overlap": 1}   # every other option defaults to 0
+ENGINE_AUTO, ENGINE_GENERIC, ENGINE_STREAM = 0, 1, 2
+ENGINES = {"auto": ENGINE_AUTO, "generic": ENGINE_GENERIC, "stream": ENGINE_STREAM}
+
+# Options every Decoder of this process applies before its next call, unless it has been given its own
+# (Decoder.set_option).  Tests and measurement scripts switch engines here, for decoders that already
+# exist as well; the library itself keeps options per context and reads no environment while decoding.
+_default_options = {}
+_default_options_version = 0
+
+
+def set_default_options(**options):
+    """Replace the process-wide option defaults, e.g. set_default_options(engine="stream", stream_kernel=1);
+    called without arguments it goes back to the library's own defaults."""
+    global _default_options, _default_options_version
+    for k in options:
+        if k not in OPT or k in OPT_READ_ONLY:
+            raise KeyError("unknown or read-only option %r" % k)
+    _default_options = dict(options)
+    _default_options_version += 1
 
 _vp, _i32, _i64, _u64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
 
@@ -36,6 +64,9 @@ SIGNATURES = {
     "ldpc_amd_graph": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ldpc_amd_set_cn_rule": (C.c_int, [_vp, _i32]),
     "ldpc_amd_set_workspace_limit": (C.c_int, [_vp, _u64]),
+    "ldpc_amd_set_option": (C.c_int, [_vp, _i32, _i64]),
+    "ldpc_amd_get_option": (C.c_int, [_vp, _i32, C.POINTER(_i64)]),
+    "ldpc_amd_last_warning": (C.c_char_p, [_vp]),
     "ldpc_amd_decode_batch": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "ldpc_amd_decode_batch_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ldpc_amd_decode_bsc_batch": (C.c_int, [_vp, _vp, _i64, _f64, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -154,6 +185,8 @@ class Decoder:
         if rc != OK:
             raise LdpcError(rc, (lib.ldpc_amd_last_error(None) or b"").decode())
         self._lib, self._h = lib, h
+        self._own_options = {}
+        self._options_version = 0   # the library's defaults are in force
         mm, nn, ee, dc, dv = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32(), C.c_int32()
         lib.ldpc_amd_info(h, C.byref(mm), C.byref(nn), C.byref(ee), C.byref(dc), C.byref(dv))
         self.m, self.n, self.E, self.max_dc, self.max_dv = mm.value, nn.value, ee.value, dc.value, dv.value
@@ -194,6 +227,33 @@ class Decoder:
     def set_cn_rule(self, rule):
         self._check(self._lib.ldpc_amd_set_cn_rule(self._h, int(rule)))
 
+    def set_option(self, name, value):
+        """An option of this decoder alone; it overrides the process-wide defaults (set_default_options)."""
+        if isinstance(value, str):
+            value = ENGINES[value]
+        self._check(self._lib.ldpc_amd_set_option(self._h, OPT[name], int(value)))
+        self._own_options[name] = int(value)
+
+    def get_option(self, name):
+        v = _i64()
+        self._check(self._lib.ldpc_amd_get_option(self._h, OPT[name], C.byref(v)))
+        return v.value
+
+    def last_warning(self):
+        return (self._lib.ldpc_amd_last_warning(self._h) or b"").decode()
+
+    def _sync_options(self):
+        if self._options_version == _default_options_version:
+            return
+        for name, key in OPT.items():
+            if name in OPT_READ_ONLY or name in self._own_options:
+                continue
+            value = _default_options.get(name, OPT_LIBRARY_DEFAULT.get(name, 0))
+            if isinstance(value, str):
+                value = ENGINES[value]
+            self._check(self._lib.ldpc_amd_set_option(self._h, key, int(value)))
+        self._options_version = _default_options_version
+
     def set_workspace_limit(self, nbytes):
         self._check(self._lib.ldpc_amd_set_workspace_limit(self._h, int(nbytes)))
 
@@ -213,6 +273,7 @@ class Decoder:
         llr = np.ascontiguousarray(llr, dtype=np.float32)
         if llr.ndim != 2 or llr.shape[1] != self.n:
             raise ValueError("llr must be [frames][n]")
+        self._sync_options()
         f = llr.shape[0]
         hard = np.zeros((f, self.n), np.uint8)
         it = np.zeros(f, np.int32)
@@ -225,6 +286,7 @@ class Decoder:
         r = np.ascontiguousarray(r, dtype=np.uint8)
         if r.ndim != 2 or r.shape[1] != self.n:
             raise ValueError("r must be [frames][n]")
+        self._sync_options()
         f = r.shape[0]
         hard = np.zeros((f, self.n), np.uint8)
         it = np.zeros(f, np.int32)
@@ -237,18 +299,21 @@ class Decoder:
         if counters is None:
             counters = np.zeros(CNT_FIXED + int(max_iters), np.uint64)
         assert counters.dtype == np.uint64 and counters.size >= CNT_FIXED + int(max_iters)
+        self._sync_options()
         self._check(self._lib.ldpc_amd_simulate(self._h, int(channel), float(param), int(seed), int(first_frame),
                                                 int(frames), int(max_iters), int(bool(early_term)), _np_ptr(counters)))
         return counters
 
     # ---- device-pointer entry points (addresses as ints, e.g. torch.Tensor.data_ptr()) ---
     def decode_batch_dev(self, d_llr, frames, max_iters, early_term, d_hard, d_iters=0, d_synd=0, stream=0):
+        self._sync_options()
         self._check(self._lib.ldpc_amd_decode_batch_dev(self._h, d_llr, int(frames), int(max_iters),
                                                         int(bool(early_term)), d_hard, d_iters or None,
                                                         d_synd or None, stream or None))
 
     def decode_bsc_batch_dev(self, d_r, frames, e, llr_mode, max_iters, early_term, d_hard, d_iters=0, d_synd=0,
                              stream=0):
+        self._sync_options()
         self._check(self._lib.ldpc_amd_decode_bsc_batch_dev(self._h, d_r, int(frames), float(e), int(llr_mode),
                                                             int(max_iters), int(bool(early_term)), d_hard,
                                                             d_iters or None, d_synd or None, stream or None))

@@ -65,7 +65,6 @@ struct BpParams {
     int32_t* out_iters;      // [frames_total] or null
     int32_t* out_synd;       // [frames_total] or null
     int lds_maxd;            // rows of LDS staging per wave and array (0 = no LDS path)
-    int skip;                // timing experiments only: bit 0 skips the CN sweeps, bit 1 the VN sweeps
 };
 
 // ---- vector access helpers: FPL consecutive floats / words per lane -------------------
@@ -893,11 +892,9 @@ __global__ void __launch_bounds__(256, WPS) bp_decode_kernel(BpParams p) {
         }
     } else {
         for (int it = 0; it < p.max_iters; ++it) {
-            if (!(p.skip & 1)) {
-                if (it == 0) cn_sweep<FPL, RULE, true, DC>(p, msg, lam, lds, lane);
-                else         cn_sweep<FPL, RULE, false, DC>(p, msg, lam, lds, lane);
-            }
-            if (!(p.skip & 2)) vn_sweep<FPL, DV>(p, msg, lam, bits, it + 1 < p.max_iters, lds, lane);
+            if (it == 0) cn_sweep<FPL, RULE, true, DC>(p, msg, lam, lds, lane);
+            else         cn_sweep<FPL, RULE, false, DC>(p, msg, lam, lds, lane);
+            vn_sweep<FPL, DV>(p, msg, lam, bits, it + 1 < p.max_iters, lds, lane);
         }
         int w[FPL];
         syndrome_sweep<FPL>(p, bits, w);

@@ -46,7 +46,8 @@ hipError_t bp_nodes_launch(const NodesLaunch& l, const NodesParams& p) {
     if (p.frames < 1 || p.frames > kNodesMaxFrames || p.max_iters < 1 || l.max_blocks < 1) return hipErrorInvalidValue;
     const long long items = (long long)p.frames * (((long long)std::max(p.m, p.n) + 63) / 64 * 64);
     const long long want = (items + 255) / 256;
-    const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(want, l.max_blocks))), block(256);
+    const dim3 grid((unsigned)(l.force_blocks > 0 ? l.force_blocks : std::max<long long>(1, std::min<long long>(want, l.max_blocks)))),
+        block(256);
     NodesParams q = p;
     void* args[] = {&q};
     return hipLaunchCooperativeKernel(kernel_of(l.rule), grid, block, args, 0, l.stream);

@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
 struct NodesLaunch {
     int rule;
     int max_blocks;  // blocks of 256 threads that can be resident at once on the device (0: ask)
+    int force_blocks = 0;  // tests only: launch exactly this many blocks, also when they cannot be resident
     hipStream_t stream;
 };
 

@@ -23,8 +23,21 @@
 
 using namespace ldpc;
 
+// Per-context switches (ldpc_amd_set_option); 0 in a tuning field = the library's own choice.
+struct Options {
+    int engine = LDPC_AMD_ENGINE_AUTO;
+    int stream_kernel = 0;
+    int nodes = -1;
+    int sim_overlap = 1;
+    int verbose = 0;
+    int lds_wpe = 0, lds_fpw = 0, generic_lds_kb = 0, nodes_blocks = 0, fpl = 0, layout = 0, rows_waves = 0, wps = 0,
+        nopipe = 0;
+    int test_nodes_oversize = 0;
+};
+
 struct ldpc_amd_ctx {
     int device = 0;
+    Options opt;
     int m = 0, n = 0, nw = 0;
     long long E = 0;
     int max_dc = 0, max_dv = 0;
@@ -60,6 +73,9 @@ struct ldpc_amd_ctx {
     int gen_nt = 0, gen_cn_steps = 0, gen_vn_steps = 0, gen_slots = 0;
     // node-parallel cooperative engine: blocks that can be resident at once (0: not asked yet, -1: not available)
     int nodes_blocks = 0;
+    long long nodes_refusals = 0;   // cooperative launches the runtime refused
+    int nodes_refused_in_a_row = 0;
+    int nodes_last_error = 0;       // hipError_t of the last refusal
     int* d_genres = nullptr;
     // timing of the last decode
     std::vector<hipEvent_t> ev;
@@ -67,6 +83,7 @@ struct ldpc_amd_ctx {
     long long timed_frames = 0;
     const char* last_kernel = "";  // which message-passing kernel the last decode ran
     std::string err;
+    std::string warn;  // last event that did not fail a call (ldpc_amd_last_warning)
 };
 
 namespace {
@@ -230,7 +247,7 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt) {
     LDPC_HIP(c, hipMalloc((void**)&c->d_res, tab.size() * sizeof(int)));
     LDPC_HIP(c, hipMemcpy(c->d_res, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
     c->res_nt = nt;
-    if (getenv("LDPC_AMD_VERBOSE"))
+    if (c->opt.verbose)
         fprintf(stderr, "ldpc_amd: resident tables nt=%d, mean worst bank multiplicity of VN gathers %.3f\n", nt,
                 c->res_conflict);
     return LDPC_AMD_OK;
@@ -337,7 +354,7 @@ int launch_bp(ldpc_amd_ctx* c, const BpParams& p, int fpl, bool early, int wpb, 
              : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
     l.early = early;
     l.wps = fpl == 4 ? 2 : 4;  // 4 frames per lane need ~180 VGPRs to stay out of scratch
-    if (const char* env = getenv("LDPC_AMD_WPS")) l.wps = atoi(env) == 2 ? 2 : 4;
+    if (c->opt.wps) l.wps = c->opt.wps == 2 ? 2 : 4;
     l.grid = dim3((unsigned)((p.tiles + wpb - 1) / wpb));
     l.block = dim3((unsigned)(64 * wpb));
     l.lds_bytes = lds_bytes;
@@ -347,6 +364,21 @@ int launch_bp(ldpc_amd_ctx* c, const BpParams& p, int fpl, bool early, int wpb, 
     else bp_launch_generic(l, p);
     LDPC_HIP(c, hipGetLastError());
     return LDPC_AMD_OK;
+}
+
+// The runtime refused a cooperative launch of the node-parallel kernel: count it and keep the reason.
+void note_nodes_refusal(ldpc_amd_ctx* c, hipError_t e, int blocks, bool retrying) {
+    c->nodes_refusals++;
+    c->nodes_last_error = (int)e;
+    c->warn = std::string("cooperative launch of bp_nodes_kernel refused: ") + hipGetErrorName(e) + " (" +
+              hipGetErrorString(e) + "), grid of " + std::to_string(blocks) + " blocks of 256 threads; " +
+              (retrying ? "retrying with half the grid" : "the batch was decoded by the sweep launches");
+    if (c->opt.verbose) fprintf(stderr, "ldpc_amd: %s\n", c->warn.c_str());
+}
+
+// Bytes of streaming workspace one tile of T frames takes: messages, LLRs, packed decisions, 4 state words.
+size_t stream_tile_bytes(const ldpc_amd_ctx* c, int T) {
+    return ((size_t)c->E + (size_t)c->n + (size_t)c->nw + 4) * (size_t)T * sizeof(float);
 }
 
 int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_iters, int early_term, uint8_t* d_hard,
@@ -372,9 +404,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         const size_t lds_bytes = ((size_t)c->E + (size_t)c->nw + 4 + (size_t)(c->m + 31) / 32) * sizeof(float);
         bool use = shape && n % (kLdsVpt * 64) == 0 && nt <= 512 && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll &&
                    c->m <= 2048;  // the convergence test reads the syndrome words with one wavefront
-        if (const char* env = getenv("LDPC_AMD_ENGINE")) {
-            if (!strcmp(env, "stream") || !strcmp(env, "generic")) use = false;
-        }
+        if (c->opt.engine != LDPC_AMD_ENGINE_AUTO) use = false;
         if (use) {
             if (int rc = build_resident_tables(c, nt)) return rc;
             LdsParams q{};
@@ -393,11 +423,11 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             // measured: three workgroups per CU (80 registers) pay off for the (6,3) kernels; the (8,2)
             // kernels lose more to register spills than they gain in occupancy
             l.wpe = c->reg_dc == 6 ? 6 : 4;
-            if (const char* env = getenv("LDPC_AMD_LDS_WPE")) l.wpe = atoi(env);
+            if (c->opt.lds_wpe) l.wpe = c->opt.lds_wpe;
             // with early termination a workgroup takes several frames in turn, once there are enough of
             // them to keep every CU supplied with workgroups that finish at different times
             l.frames_per_wg = early ? (int)std::max<long long>(1, std::min<long long>(8, frames / 16384)) : 1;
-            if (const char* env = getenv("LDPC_AMD_LDS_FPW")) l.frames_per_wg = std::max(1, atoi(env));
+            if (c->opt.lds_fpw) l.frames_per_wg = std::max(1, c->opt.lds_fpw);
             while (c->ev.size() < 2) {
                 hipEvent_t e;
                 LDPC_HIP(c, hipEventCreate(&e));
@@ -419,9 +449,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         const int nt = std::min(512, std::max(64, ((std::max(n, c->m) + 7) / 8 + 63) / 64 * 64));
         bool use = c->m > 0 && c->max_dc <= kLdsGenMaxDc && c->max_dv <= kLdsGenMaxDv && frames <= 0x7fffffffll &&
                    (size_t)c->E * sizeof(float) <= 160 * 1024;
-        if (const char* env = getenv("LDPC_AMD_ENGINE")) {
-            if (!strcmp(env, "stream")) use = false;
-        }
+        if (c->opt.engine == LDPC_AMD_ENGINE_STREAM) use = false;
         size_t lds_bytes = 0;
         int nwp = 0;
         if (use) {
@@ -432,7 +460,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             // up to the whole LDS of a CU: even at one workgroup per CU this engine measured 1.5x (fixed
             // iterations) to 3x (early exit) the streaming engine
             size_t lds_limit = 160 * 1024;
-            if (const char* env = getenv("LDPC_AMD_GENERIC_LDS_KB")) lds_limit = (size_t)atoi(env) * 1024;  // experiments
+            if (c->opt.generic_lds_kb) lds_limit = c->opt.generic_lds_kb < 0 ? 0 : (size_t)c->opt.generic_lds_kb * 1024;  // measurements
             use = lds_bytes <= lds_limit && c->gen_vn_steps <= 16;  // 2 decision bits per step in one register
         }
         if (use) {
@@ -474,23 +502,15 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     // Node-parallel cooperative engine: a batch of at most 32 frames of a code the resident engines do
     // not take runs in one launch with one thread per node (a lane per frame would leave the chip empty).
     {
-        bool use = frames <= kNodesMaxFrames && c->m > 0 && c->max_dc <= kNodesMaxDc && c->max_dv <= kNodesMaxDv &&
-                   c->nodes_blocks >= 0;
-        if (const char* env = getenv("LDPC_AMD_ENGINE")) {
-            if (!strcmp(env, "stream")) use = false;
-        }
+        const bool can = frames <= kNodesMaxFrames && c->m > 0 && c->max_dc <= kNodesMaxDc && c->max_dv <= kNodesMaxDv &&
+                         c->nodes_blocks >= 0 && c->opt.engine != LDPC_AMD_ENGINE_STREAM;
+        bool use = can;
         // Per iteration this engine costs two grid barriers (about 20 us) plus about 64 ns per 1000 edges of
         // the batch (gathers of single words); the sweep launches cost about 100 us of launches plus the
         // longest wave's chain of dependent nodes, 32 variables of the largest degree (measured on an
         // NR-BG1-sized code and on a (3,6) code of n = 64800: break-even at 32 and at 7 frames).
         use = use && 20.0 + 6.4e-5 * (double)frames * (double)c->E < 100.0 + 5.8 * c->max_dv;
-        if (const char* env = getenv("LDPC_AMD_NODES")) {  // 0: never, 1: whenever the batch and the degrees allow
-            use = atoi(env) != 0 && frames <= kNodesMaxFrames && c->m > 0 && c->max_dc <= kNodesMaxDc &&
-                  c->max_dv <= kNodesMaxDv && c->nodes_blocks >= 0;
-            if (const char* eng = getenv("LDPC_AMD_ENGINE")) {
-                if (!strcmp(eng, "stream")) use = false;
-            }
-        }
+        if (c->opt.nodes >= 0) use = can && c->opt.nodes != 0;  // 0: never, 1: whenever the batch and the degrees allow
         if (use && c->nodes_blocks == 0) {
             int coop = 0, blocks = 0;
             LDPC_HIP(c, hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device));
@@ -529,32 +549,45 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             // the grid-wide barrier costs about 0.1 us per block, the phases shrink with the blocks they are
             // spread over: measured optimum near 64 blocks for one frame, 128 for eight
             l.max_blocks = std::min(c->nodes_blocks, 48 + 16 * (int)frames); l.stream = s;
-            if (const char* env = getenv("LDPC_AMD_NODES_BLOCKS"))  // experiments: a smaller grid
-                l.max_blocks = std::max(1, std::min(c->nodes_blocks, atoi(env)));
+            if (c->opt.nodes_blocks)  // measurements: a smaller grid
+                l.max_blocks = std::max(1, std::min(c->nodes_blocks, c->opt.nodes_blocks));
+            // tests: a grid of four times what can be resident, which the runtime must refuse at launch
+            if (c->opt.test_nodes_oversize) l.max_blocks = l.force_blocks = 4 * c->nodes_blocks;
             while (c->ev.size() < 2) {
                 hipEvent_t e;
                 LDPC_HIP(c, hipEventCreate(&e));
                 c->ev.push_back(e);
             }
             LDPC_HIP(c, hipEventRecord(c->ev[0], s));
-            if (bp_nodes_launch(l, q) == hipSuccess) {
+            hipError_t le = bp_nodes_launch(l, q);
+            if (le == hipErrorCooperativeLaunchTooLarge && !l.force_blocks && l.max_blocks > 1) {
+                // the occupancy query counts an empty device: with other work resident fewer blocks fit.
+                // Nothing has run; one more try with half the grid (the kernel strides over its items).
+                (void)hipGetLastError();
+                note_nodes_refusal(c, le, l.max_blocks, true);
+                l.max_blocks /= 2;
+                le = bp_nodes_launch(l, q);
+            }
+            if (le == hipSuccess) {
                 LDPC_HIP(c, hipEventRecord(c->ev[1], s));
                 c->timed_launches = 1;
                 c->timed_frames = frames;
                 c->last_kernel = "bp_nodes_kernel";
+                c->nodes_refused_in_a_row = 0;
                 return LDPC_AMD_OK;
             }
-            // the runtime would not start the grid as a whole (nothing has run): this context leaves the
-            // engine alone from now on, and the batch goes through the sweep launches below
+            // The runtime would not start the grid as a whole, so nothing has run: this batch goes through the
+            // sweep launches below.  The refusal is counted and kept (ldpc_amd_get_option, ldpc_amd_last_warning);
+            // after three in a row the context stops asking until LDPC_AMD_OPT_NODES is set again.
             (void)hipGetLastError();
-            c->nodes_blocks = -1;
+            note_nodes_refusal(c, le, l.max_blocks, false);
+            if (++c->nodes_refused_in_a_row >= 3) c->nodes_blocks = -1;
         }
     }
     const int maxdeg = std::max(c->max_dc, c->max_dv);
     if (maxdeg > kLdsMaxDegree) return fail(c, LDPC_AMD_ELIMIT, "node degree above 128 is not supported");
     int fpl = (!early && maxdeg <= kRegDegFpl4) ? 4 : 1;
-    if (const char* env = getenv("LDPC_AMD_FPL")) {
-        const int v = atoi(env);
+    if (const int v = c->opt.fpl) {
         if (!early && maxdeg <= kRegDegFpl4 && (v == 1 || v == 2 || v == 4)) fpl = v;
     }
     const int T = 64 * fpl;
@@ -566,7 +599,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
 
     const long long tiles_total = (frames + T - 1) / T;
     // + 4 words of per-frame state for the row-parallel launches
-    const size_t per_tile = ((size_t)c->E + (size_t)n + (size_t)c->nw + 4) * T * sizeof(float);
+    const size_t per_tile = stream_tile_bytes(c, T);
     unsigned long long limit = c->ws_limit;
     if (!limit) {
         size_t fr = 0, tot = 0;
@@ -578,14 +611,12 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     if (max_tiles > (1ll << 30)) max_tiles = 1ll << 30;
     // layout 0: [tile][row][T]  (a tile's rows are contiguous)
     // layout 1: [row][tile][T]  (the same row of neighbouring tiles is contiguous)
-    int layout = 0;
-    if (const char* env = getenv("LDPC_AMD_LAYOUT")) layout = atoi(env) ? 1 : 0;
+    const int layout = c->opt.layout ? 1 : 0;
     // Every sweep is its own launch over (tile, row chunk) pairs, cut as finely as the packed decision
     // words allow (32 variables per wave): short uniform waves walk through the tiles in address order,
     // a wave whose frames have all converged ends at once, and a batch of any size fills the chip.
-    // LDPC_AMD_ROWS=0 selects the other streaming kernel, one wave per tile for the whole decode.
-    bool by_rows = layout == 0 && fpl != 2;
-    if (const char* env = getenv("LDPC_AMD_ROWS")) by_rows = by_rows && atoi(env) != 0;
+    // LDPC_AMD_OPT_STREAM_KERNEL = 1 selects the other streaming kernel, one wave per tile for the whole decode.
+    const bool by_rows = layout == 0 && fpl != 2 && c->opt.stream_kernel == 0;
     if (by_rows) max_tiles = std::min<long long>(max_tiles, 65535);  // tiles are the grid's y dimension
     const long long rounds = (tiles_total + max_tiles - 1) / max_tiles;
     const long long tiles_per_round = (tiles_total + rounds - 1) / rounds;
@@ -624,14 +655,12 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     p.frames_total = frames; p.max_iters = max_iters;
     p.out_iters = d_iters; p.out_synd = d_synd;
     p.lds_maxd = lds_maxd;
-    if (const char* env = getenv("LDPC_AMD_SKIP")) p.skip = atoi(env);  // timing experiments only
-    bool pipelined = true;
-    if (const char* env = getenv("LDPC_AMD_NOPIPE")) pipelined = atoi(env) == 0;  // A/B: per-row dispatch kernels
+    const bool pipelined = c->opt.nopipe == 0;  // A/B: per-row dispatch kernels
     int chunks = 1, rows_per_chunk = c->m, vars_per_chunk = (n + 31) / 32 * 32;
     if (by_rows) {
         chunks = std::max(1, std::min(4096, std::min(c->m / 4, n / 32)));
-        if (const char* env = getenv("LDPC_AMD_ROWS_WAVES"))  // experiments: waves per launch
-            chunks = (int)std::max<long long>(1, std::min<long long>(chunks, (std::max(256, atoi(env)) + tiles_per_round - 1) / tiles_per_round));
+        if (c->opt.rows_waves)  // measurements: waves per launch
+            chunks = (int)std::max<long long>(1, std::min<long long>(chunks, (std::max(256, c->opt.rows_waves) + tiles_per_round - 1) / tiles_per_round));
         rows_per_chunk = (c->m + chunks - 1) / chunks;
         vars_per_chunk = ((n + chunks - 1) / chunks + 31) / 32 * 32;
         c->last_kernel = "rows_cn_kernel";
@@ -815,6 +844,7 @@ int ldpc_amd_create(int32_t m, int32_t n, int64_t nnz, const int32_t* row_idx, c
     ldpc_amd_ctx* c = new (std::nothrow) ldpc_amd_ctx();
     if (!c) return fail(nullptr, LDPC_AMD_ENOMEM, "create: out of host memory");
     c->device = dev;
+    if (const char* env = getenv("LDPC_AMD_VERBOSE")) c->opt.verbose = atoi(env) != 0 || env[0] == '\0' ? 1 : 0;
     c->m = m; c->n = n; c->nw = (n + 31) / 32;
     build_graph(c, nnz, row_idx, col_idx);
     DeviceGuard guard(dev);
@@ -892,6 +922,68 @@ int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* c, uint64_t bytes) {
     c->ws_limit = bytes;
     return LDPC_AMD_OK;
 }
+
+int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
+    if (!c) return LDPC_AMD_EINVAL;
+    auto range = [&](int64_t lo, int64_t hi) { return value >= lo && value <= hi; };
+    Options& o = c->opt;
+    const int v = (int)value;
+    switch (key) {
+        case LDPC_AMD_OPT_ENGINE: if (!range(0, 2)) break; o.engine = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_STREAM_KERNEL: if (!range(0, 1)) break; o.stream_kernel = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_NODES:
+            if (!range(-1, 1)) break;
+            o.nodes = v;
+            if (c->nodes_blocks < 0) c->nodes_blocks = 0;  // ask the runtime again
+            c->nodes_refused_in_a_row = 0;
+            return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_SIM_OVERLAP: if (!range(0, 1)) break; o.sim_overlap = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_VERBOSE: if (!range(0, 1)) break; o.verbose = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_LDS_WPE: if (!(value == 0 || value == 4 || value == 6)) break; o.lds_wpe = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_LDS_FPW: if (!range(0, 1 << 20)) break; o.lds_fpw = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_GENERIC_LDS_KB: if (!range(-1, 160)) break; o.generic_lds_kb = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_NODES_BLOCKS: if (!range(0, 1 << 20)) break; o.nodes_blocks = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_FPL: if (!(value == 0 || value == 1 || value == 2 || value == 4)) break; o.fpl = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_LAYOUT: if (!range(0, 1)) break; o.layout = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_ROWS_WAVES: if (!range(0, 1 << 30)) break; o.rows_waves = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_WPS: if (!(value == 0 || value == 2 || value == 4)) break; o.wps = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_NOPIPE: if (!range(0, 1)) break; o.nopipe = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: if (!range(0, 1)) break; o.test_nodes_oversize = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_NODES_REFUSALS:
+        case LDPC_AMD_OPT_NODES_LAST_HIP_ERROR:
+            return fail(c, LDPC_AMD_EINVAL, "set_option: key " + std::to_string(key) + " is read-only");
+        default: return fail(c, LDPC_AMD_EINVAL, "set_option: unknown key " + std::to_string(key));
+    }
+    return fail(c, LDPC_AMD_EINVAL, "set_option: value " + std::to_string(value) + " is out of range for key " + std::to_string(key));
+}
+
+int ldpc_amd_get_option(const ldpc_amd_ctx* c, int32_t key, int64_t* value) {
+    if (!c || !value) return LDPC_AMD_EINVAL;
+    const Options& o = c->opt;
+    switch (key) {
+        case LDPC_AMD_OPT_ENGINE: *value = o.engine; break;
+        case LDPC_AMD_OPT_STREAM_KERNEL: *value = o.stream_kernel; break;
+        case LDPC_AMD_OPT_NODES: *value = o.nodes; break;
+        case LDPC_AMD_OPT_SIM_OVERLAP: *value = o.sim_overlap; break;
+        case LDPC_AMD_OPT_VERBOSE: *value = o.verbose; break;
+        case LDPC_AMD_OPT_TUNE_LDS_WPE: *value = o.lds_wpe; break;
+        case LDPC_AMD_OPT_TUNE_LDS_FPW: *value = o.lds_fpw; break;
+        case LDPC_AMD_OPT_TUNE_GENERIC_LDS_KB: *value = o.generic_lds_kb; break;
+        case LDPC_AMD_OPT_TUNE_NODES_BLOCKS: *value = o.nodes_blocks; break;
+        case LDPC_AMD_OPT_TUNE_FPL: *value = o.fpl; break;
+        case LDPC_AMD_OPT_TUNE_LAYOUT: *value = o.layout; break;
+        case LDPC_AMD_OPT_TUNE_ROWS_WAVES: *value = o.rows_waves; break;
+        case LDPC_AMD_OPT_TUNE_WPS: *value = o.wps; break;
+        case LDPC_AMD_OPT_TUNE_NOPIPE: *value = o.nopipe; break;
+        case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: *value = o.test_nodes_oversize; break;
+        case LDPC_AMD_OPT_NODES_REFUSALS: *value = c->nodes_refusals; break;
+        case LDPC_AMD_OPT_NODES_LAST_HIP_ERROR: *value = c->nodes_last_error; break;
+        default: return LDPC_AMD_EINVAL;
+    }
+    return LDPC_AMD_OK;
+}
+
+const char* ldpc_amd_last_warning(const ldpc_amd_ctx* c) { return c ? c->warn.c_str() : ""; }
 
 int ldpc_amd_decode_batch_dev(ldpc_amd_ctx* c, const float* d_llr, int64_t frames, int32_t max_iters,
                               int32_t early_term, uint8_t* d_hard, int32_t* d_iters, int32_t* d_synd, void* stream) {
@@ -1126,8 +1218,7 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
         if (rc) return rc;
         if (index == 0) {
             const char* k = c->last_kernel;
-            overlap = k && (!strcmp(k, "bp_lds_kernel") || !strcmp(k, "bp_lds_gen_kernel"));
-            if (const char* env = getenv("LDPC_AMD_SIM_OVERLAP")) overlap = overlap && atoi(env) != 0;
+            overlap = k && (!strcmp(k, "bp_lds_kernel") || !strcmp(k, "bp_lds_gen_kernel")) && c->opt.sim_overlap != 0;
         }
     }
     LDPC_HIP(c, hipStreamSynchronize(c->io_stream[0]));

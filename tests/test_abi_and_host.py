@@ -27,7 +27,23 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in names:
         assert hasattr(lib, name), "libldpc_amd.so does not export %s" % name
     assert sorted(pkg.capi.SIGNATURES) == names, "capi.SIGNATURES and include/ldpc_amd.h disagree"
-    assert lib.ldpc_amd_version() == 100
+    header = open(os.path.join(ROOT, "include", "ldpc_amd.h")).read()
+    assert lib.ldpc_amd_version() == int(re.search(r"#define LDPC_AMD_VERSION (\d+)", header).group(1))
+    # every option key of the header is known to the binding under the same number
+    keys = dict(re.findall(r"#define LDPC_AMD_OPT_([A-Z_]+) (\d+)", header))
+    assert {k.lower().replace("tune_", ""): int(v) for k, v in keys.items()} == pkg.capi.OPT
+
+
+def test_product_library_reads_no_environment_while_decoding():
+    """Engine choice is a per-context option; the only getenv in the library is the one in ldpc_amd_create."""
+    csrc = os.path.join(ROOT, "ldpc-simulator_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+                if "getenv" in line:
+                    hits.append((f, i, line.strip()))
+    assert len(hits) == 1 and "LDPC_AMD_VERBOSE" in hits[0][2], hits
 
 
 def test_no_cpu_fallback(pkg):

@@ -1,25 +1,16 @@
 """The node-parallel cooperative engine (very small batches of codes that do not live in LDS): against the
 double-precision oracle, and bit for bit against the row-parallel sweeps on the same inputs."""
-import os
-
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-KEYS = ("LDPC_AMD_ENGINE", "LDPC_AMD_ROWS", "LDPC_AMD_NODES", "LDPC_AMD_GENERIC_LDS_KB")
-
 
 @pytest.fixture(autouse=True)
-def clean_env():
-    old = {k: os.environ.get(k) for k in KEYS}
-    for k in KEYS:
-        os.environ.pop(k, None)
+def library_defaults(pkg):
+    pkg.capi.set_default_options()
     yield
-    for k in KEYS:
-        os.environ.pop(k, None)
-        if old[k] is not None:
-            os.environ[k] = old[k]
+    pkg.capi.set_default_options()
 
 
 def _syndrome_weight_sparse(m, rows, cols, hard):
@@ -30,23 +21,23 @@ def _syndrome_weight_sparse(m, rows, cols, hard):
 
 def _both(dec, call):
     """The same decode through the node-parallel engine and through the sweep launches."""
-    os.environ["LDPC_AMD_NODES"] = "1"
+    dec.set_option("nodes", 1)
     a = call()
     assert dec.last_decode_kernel() == "bp_nodes_kernel"
-    os.environ["LDPC_AMD_NODES"] = "0"
+    dec.set_option("nodes", 0)
     b = call()
     assert dec.last_decode_kernel() == "rows_cn_kernel"
-    os.environ.pop("LDPC_AMD_NODES")
+    dec.set_option("nodes", -1)
     return a, b
 
 
 def test_small_irregular_code_against_the_oracle(pkg, oracle):
     """NR-BG1-shaped code at a small lifting size (degrees 3..19 / 1..30), kept out of the resident
     engines: every check-node rule, LLR and hard-word input, 1 to 32 frames, early exit and fixed."""
-    os.environ["LDPC_AMD_GENERIC_LDS_KB"] = "0"
     _, (m, n, rows, cols) = pkg.codes.nr_bg1_shaped(z=8, seed=3)
     g = oracle.Graph(m, n, rows, cols)
     dec = pkg.Decoder(m, n, rows, cols)
+    dec.set_option("generic_lds_kb", -1)
     for F, ebn0, early, L in ((1, 2.0, True, 30), (5, 1.0, True, 20), (32, 2.5, True, 40), (32, 1.0, False, 6),
                               (7, 3.0, True, 1), (3, 0.0, False, 1)):
         llr = oracle.gen_awgn_llr(m, n, ebn0, seed=21 + F, first_frame=0, frames=F)
@@ -96,3 +87,33 @@ def test_bg1_sized_and_long_codes_identical_to_the_sweeps(pkg):
         dec.decode_batch(llr[:1], L, True)
         assert dec.last_decode_kernel() == "bp_nodes_kernel"
         dec.close()
+
+
+def test_refused_cooperative_launch_is_observable_and_not_final(pkg):
+    """A cooperative grid the runtime refuses (here: four times what can be resident, asked for through the
+    test option) must not fail the decode, must not be silent, and must not turn the engine off for good."""
+    m, n, rows, cols = pkg.codes.nr_bg1_shaped(z=384, seed=1)[1]
+    dec = pkg.Decoder(m, n, rows, cols)
+    import torch
+    F = 32
+    d_llr = torch.empty((F, n), dtype=torch.float32, device="cuda")
+    dec.gen_awgn_llr_dev(2.0, 3, 0, F, d_llr.data_ptr())
+    llr = d_llr.cpu().numpy()
+    dec.set_option("nodes", 1)
+    want = dec.decode_batch(llr, 12, True)
+    assert dec.last_decode_kernel() == "bp_nodes_kernel"
+    assert dec.get_option("nodes_refusals") == 0 and dec.last_warning() == ""
+    dec.set_option("test_nodes_oversize", 1)
+    got = dec.decode_batch(llr, 12, True)
+    assert dec.last_decode_kernel() == "rows_cn_kernel"          # the batch went through the sweeps
+    assert dec.get_option("nodes_refusals") == 1
+    assert dec.get_option("nodes_last_hip_error") != 0
+    assert "refused" in dec.last_warning() and "bp_nodes_kernel" in dec.last_warning()
+    for x, y in zip(got, want):
+        assert (x == y).all()
+    dec.set_option("test_nodes_oversize", 0)
+    again = dec.decode_batch(llr, 12, True)
+    assert dec.last_decode_kernel() == "bp_nodes_kernel"         # one refusal does not disable the engine
+    for x, y in zip(again, want):
+        assert (x == y).all()
+    dec.close()

@@ -8,33 +8,30 @@ resolve that, and the disagreeing frames are itemised in the assertion message.
 import numpy as np
 import pytest
 
-import os
-
 pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["resident", "resident_generic", "stream_tiles", "stream_rows"])
 def engine(request):
     """Codes that fit in LDS run a frame-resident engine by default: the kernels specialised for the
-    (6,3) and (8,2) regular codes, or the generic one (any degrees up to 20 / 32), which
-    LDPC_AMD_ENGINE=generic forces also where a specialised kernel exists.  Every test also runs
-    with the frame-major streaming engine forced (LDPC_AMD_ENGINE=stream), once as the one-launch
-    kernel that gives each wavefront its own tile (LDPC_AMD_ROWS=0) and once as row-parallel sweep
-    launches (LDPC_AMD_ROWS=1, the default for small batches)."""
-    keys = ("LDPC_AMD_ENGINE", "LDPC_AMD_ROWS")
-    old = {k: os.environ.get(k) for k in keys}
-    for k in keys:
-        os.environ.pop(k, None)
-    if request.param == "resident_generic":
-        os.environ["LDPC_AMD_ENGINE"] = "generic"
-    elif request.param != "resident":
-        os.environ["LDPC_AMD_ENGINE"] = "stream"
-        os.environ["LDPC_AMD_ROWS"] = "1" if request.param == "stream_rows" else "0"
+    (6,3) and (8,2) regular codes, or the generic one (any degrees up to 20 / 32), which the option
+    engine = generic forces also where a specialised kernel exists.  Every test also runs with the
+    frame-major streaming engine forced (engine = stream), once as the one-launch kernel that gives
+    each wavefront its own tile (stream_kernel = 1) and once as row-parallel sweep launches
+    (stream_kernel = 0, the default).  The options are per context (ldpc_amd_set_option); the binding
+    applies these process-wide defaults to every decoder before its next call."""
+    import ldpc_simulator_amd as L
+    L.capi.set_default_options(**ENGINE_OPTIONS[request.param])
     yield request.param
-    for k in keys:
-        os.environ.pop(k, None)
-        if old[k] is not None:
-            os.environ[k] = old[k]
+    L.capi.set_default_options()
+
+
+ENGINE_OPTIONS = {
+    "resident": {},
+    "resident_generic": {"engine": "generic"},
+    "stream_tiles": {"engine": "stream", "stream_kernel": 1},
+    "stream_rows": {"engine": "stream", "stream_kernel": 0},
+}
 
 
 def _dense(m, n, rows, cols):
@@ -205,19 +202,17 @@ def test_engines_return_identical_bits(pkg, c1, c2, oracle, engine):
     for c, ebn0, F in ((c2, 1.2, 1500), (c1, 4.0, 1500)):
         llr = oracle.gen_awgn_llr(c["m"], c["n"], ebn0, seed=12, first_frame=0, frames=F)
         for early, L in ((True, 30), (False, 9)):
-            os.environ.pop("LDPC_AMD_ENGINE", None)
+            pkg.capi.set_default_options()
             a = c["dec"].decode_batch(llr, L, early)
             assert c["dec"].last_decode_kernel() == "bp_lds_kernel"
-            for eng, rows_mode, kernel in (("generic", "0", "bp_lds_gen_kernel"), ("stream", "0", "bp_decode_kernel"),
-                                           ("stream", "1", "rows_cn_kernel")):
-                os.environ["LDPC_AMD_ENGINE"] = eng
-                os.environ["LDPC_AMD_ROWS"] = rows_mode
+            for name, kernel in (("resident_generic", "bp_lds_gen_kernel"), ("stream_tiles", "bp_decode_kernel"),
+                                 ("stream_rows", "rows_cn_kernel")):
+                pkg.capi.set_default_options(**ENGINE_OPTIONS[name])
                 b = c["dec"].decode_batch(llr, L, early)
                 assert c["dec"].last_decode_kernel() == kernel
                 for x, y in zip(a, b):
                     assert (x == y).all(), (early, L, kernel)
-            os.environ.pop("LDPC_AMD_ENGINE", None)
-            os.environ.pop("LDPC_AMD_ROWS", None)
+            pkg.capi.set_default_options()
             assert (a[2] > 0).any()
     # an irregular quasi-cyclic code: runs of equal-degree rows (grouped loads) next to single rows
     _, (m, n, rows, cols) = pkg.codes.nr_bg1_shaped(z=8, seed=5)
@@ -226,14 +221,12 @@ def test_engines_return_identical_bits(pkg, c1, c2, oracle, engine):
     for early, L in ((True, 20), (False, 7)):
         a = dec.decode_batch(llr, L, early)
         assert dec.last_decode_kernel() == "bp_lds_gen_kernel"
-        for rows_mode, kernel in (("0", "bp_decode_kernel"), ("1", "rows_cn_kernel")):
-            os.environ["LDPC_AMD_ENGINE"] = "stream"
-            os.environ["LDPC_AMD_ROWS"] = rows_mode
+        for name, kernel in (("stream_tiles", "bp_decode_kernel"), ("stream_rows", "rows_cn_kernel")):
+            pkg.capi.set_default_options(**ENGINE_OPTIONS[name])
             try:
                 b = dec.decode_batch(llr, L, early)
             finally:
-                os.environ.pop("LDPC_AMD_ENGINE", None)
-                os.environ.pop("LDPC_AMD_ROWS", None)
+                pkg.capi.set_default_options()
             assert dec.last_decode_kernel() == kernel
             for x, y in zip(a, b):
                 assert (x == y).all(), (early, L, kernel)

@@ -9,8 +9,6 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import ldpc_simulator_amd as L
 
-KEYS = ("LDPC_AMD_ENGINE", "LDPC_AMD_ROWS", "LDPC_AMD_NODES", "LDPC_AMD_GENERIC_LDS_KB")
-
 
 def random_code(rng):
     kind = rng.integers(0, 5)
@@ -36,14 +34,11 @@ def random_code(rng):
     return m, n, rows.astype(np.int32), cols.astype(np.int32)
 
 
-def run(dec, call, env):
-    for k in KEYS:
-        os.environ.pop(k, None)
-    os.environ.update(env)
+def run(dec, call, options):
+    L.capi.set_default_options(**options)
     out = call()
     kernel = dec.last_decode_kernel()
-    for k in KEYS:
-        os.environ.pop(k, None)
+    L.capi.set_default_options()
     return out, kernel
 
 
@@ -78,10 +73,10 @@ def fuzz(cases, seed):
             call = lambda: dec.decode_bsc_batch(r, e, iters, mode, early)
         else:
             call = lambda: dec.decode_batch(llr, iters, early)
-        ref, _ = run(dec, call, {"LDPC_AMD_ENGINE": "stream", "LDPC_AMD_ROWS": "1"})
-        for name, env in (("default", {}), ("generic", {"LDPC_AMD_ENGINE": "generic"}),
-                          ("one-launch", {"LDPC_AMD_ENGINE": "stream", "LDPC_AMD_ROWS": "0"}),
-                          ("nodes", {"LDPC_AMD_GENERIC_LDS_KB": "0", "LDPC_AMD_ENGINE": "generic", "LDPC_AMD_NODES": "1"})):
+        ref, _ = run(dec, call, {"engine": "stream", "stream_kernel": 0})
+        for name, env in (("default", {}), ("generic", {"engine": "generic"}),
+                          ("one-launch", {"engine": "stream", "stream_kernel": 1}),
+                          ("nodes", {"generic_lds_kb": -1, "engine": "generic", "nodes": 1})):
             out, kernel = run(dec, call, env)
             seen[kernel] = seen.get(kernel, 0) + 1
             same = all(bool((a == b).all()) for a, b in zip(out, ref))

@@ -33,9 +33,9 @@ run("C1 gallager(1024,8,2) 3 dB", L.codes.gallager(1024, 8, 2, 1), 1 << 20, 50, 
 run("C1 gallager(1024,8,2) 3 dB", L.codes.gallager(1024, 8, 2, 1), 1 << 20, 50, True, 3.0)
 run("C2 (3,6) n=4096 1.0 dB", L.codes.regular_ldpc(4096, 3, 6, 1), 1 << 18, 50, True, 1.0)
 run("C2 (3,6) n=4096 2.0 dB", L.codes.regular_ldpc(4096, 3, 6, 1), 1 << 20, 50, True, 2.0)
-os.environ["LDPC_AMD_ENGINE"] = "stream"
+L.capi.set_default_options(engine="stream")
 run("C2 (3,6) n=4096 2.0 dB [stream]", L.codes.regular_ldpc(4096, 3, 6, 1), 1 << 18, 50, True, 2.0)
-os.environ.pop("LDPC_AMD_ENGINE")
+L.capi.set_default_options()
 _, bg = L.codes.nr_bg1_shaped(384, 1)
 run("C4 BG1-shaped Z=384 2 dB", bg, 65536, 50, False, 2.0)
 run("C4 BG1-shaped Z=384 2 dB", bg, 65536, 50, True, 2.0)

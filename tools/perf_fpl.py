@@ -15,11 +15,9 @@ def run(name, code, F, iters, ebn0):
     d_hard = torch.empty((F, n), dtype=torch.uint8, device="cuda")
     d_it = torch.empty(F, dtype=torch.int32, device="cuda")
     d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
-    os.environ["LDPC_AMD_ENGINE"] = "stream"
     for rows_mode in ("0", "1"):
-        os.environ["LDPC_AMD_ROWS"] = rows_mode
         for fpl in ("1", "2", "4"):
-            os.environ["LDPC_AMD_FPL"] = fpl
+            L.capi.set_default_options(engine="stream", stream_kernel=1 - int(rows_mode), fpl=int(fpl))
             best = 1e30
             for _ in range(2):
                 dec.decode_batch_dev(d_llr.data_ptr(), F, iters, False, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
@@ -28,8 +26,7 @@ def run(name, code, F, iters, ebn0):
             print("%-24s rows=%s fpl=%s %-18s %8.1f ms %7.3f Gbit/s  algorithmic %6.0f GB/s  FER %.4f" % (
                 name, rows_mode, fpl, dec.last_decode_kernel(), best, F * (n - m) / best / 1e6, bytes_ / best / 1e6,
                 (d_sw > 0).float().mean().item()), flush=True)
-    for k in ("LDPC_AMD_ENGINE", "LDPC_AMD_ROWS", "LDPC_AMD_FPL"):
-        os.environ.pop(k, None)
+    L.capi.set_default_options()
     dec.close()
 
 

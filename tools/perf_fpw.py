@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Frame-resident kernel: frames per workgroup (LDPC_AMD_LDS_FPW) and waves per SIMD (LDPC_AMD_LDS_WPE)."""
+"""Frame-resident kernel: frames per workgroup (option lds_fpw) and waves per SIMD (option lds_wpe)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,8 +20,7 @@ for name, code, cases in (("C2", L.codes.regular_ldpc(4096, 3, 6, 1), ((1.0, Fal
         for wpe in (4, 6):
             line = "%s %.1f dB early=%d max_iters=%2d wpe=%d:" % (name, ebn0, early, iters, wpe)
             for fpw in (1, 2, 4, 8, 16):
-                os.environ["LDPC_AMD_LDS_WPE"] = str(wpe)
-                os.environ["LDPC_AMD_LDS_FPW"] = str(fpw)
+                L.capi.set_default_options(lds_wpe=wpe, lds_fpw=fpw)
                 best = 1e30
                 for _ in range(3):
                     dec.decode_batch_dev(d_llr.data_ptr(), F, iters, early, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())

@@ -16,9 +16,7 @@ def run(name, code, F, iters, early, ebn0):
     d_it = torch.empty(F, dtype=torch.int32, device="cuda")
     d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
     for eng in ("", "generic", "stream"):
-        os.environ.pop("LDPC_AMD_ENGINE", None)
-        if eng:
-            os.environ["LDPC_AMD_ENGINE"] = eng
+        L.capi.set_default_options(engine=eng or "auto")
         best = 1e30
         for _ in range(3):
             dec.decode_batch_dev(d_llr.data_ptr(), F, iters, early, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
@@ -26,7 +24,7 @@ def run(name, code, F, iters, early, ebn0):
         print("%-30s E=%6d early=%d %-8s %-18s %8.1f ms %7.3f Gbit/s  mean iters %.1f FER %.4f" % (
             name, dec.E, early, eng or "default", dec.last_decode_kernel(), best, F * (n - m) / best / 1e6,
             d_it.float().mean().item(), (d_sw > 0).float().mean().item()), flush=True)
-    os.environ.pop("LDPC_AMD_ENGINE", None)
+    L.capi.set_default_options()
     dec.close()
 
 

@@ -12,7 +12,7 @@ for n in (6144, 8192):
     for early, ebn0, iters in ((False, 1.0, 50), (True, 2.0, 50)):
         dec.gen_awgn_llr_dev(ebn0, 1, 0, F, d_llr.data_ptr())
         for kb in ("80", "160"):
-            os.environ["LDPC_AMD_GENERIC_LDS_KB"] = kb
+            L.capi.set_default_options(generic_lds_kb=int(kb))
             best = 1e9
             for _ in range(2):
                 dec.decode_batch_dev(d_llr.data_ptr(), F, iters, early, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())

@@ -14,7 +14,7 @@ def run(name, code, F, iters, early, ebn0):
     dec.gen_awgn_llr_dev(ebn0, 1, 0, F, d_llr.data_ptr())
     res = {}
     for eng in ("nodes", "rows"):
-        os.environ["LDPC_AMD_NODES"] = "1" if eng == "nodes" else "0"
+        L.capi.set_default_options(nodes=1 if eng == "nodes" else 0)
         d_hard = torch.full((F, n), 7, dtype=torch.uint8, device="cuda")
         d_it = torch.full((F,), -1, dtype=torch.int32, device="cuda")
         d_sw = torch.full((F,), -1, dtype=torch.int32, device="cuda")
@@ -29,7 +29,7 @@ def run(name, code, F, iters, early, ebn0):
         res[eng] = (d_hard.cpu(), d_it.cpu(), d_sw.cpu())
         print("%-26s F=%3d early=%d %-6s %-16s kernel %8.3f ms  wall %8.3f ms  mean iters %.1f  unsatisfied frames %d" % (
             name, F, early, eng, dec.last_decode_kernel(), best, wall, d_it.float().mean().item(), int((d_sw > 0).sum())), flush=True)
-    os.environ.pop("LDPC_AMD_NODES", None)
+    L.capi.set_default_options()
     same = all(bool((a == b).all()) for a, b in zip(res["nodes"], res["rows"]))
     print("    identical outputs:", same, flush=True)
     dec.close()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Node-parallel engine: kernel time against the number of blocks in the cooperative grid (LDPC_AMD_NODES_BLOCKS)."""
+"""Node-parallel engine: kernel time against the number of blocks in the cooperative grid (option nodes_blocks)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,7 +16,7 @@ def run(name, code, F, iters, early, ebn0, grids):
     d_it = torch.empty(F, dtype=torch.int32, device="cuda")
     d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
     for g in grids:
-        os.environ["LDPC_AMD_NODES_BLOCKS"] = str(g)
+        L.capi.set_default_options(nodes_blocks=g)
         best = 1e30
         for _ in range(3):
             dec.decode_batch_dev(d_llr.data_ptr(), F, iters, early, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
@@ -24,7 +24,7 @@ def run(name, code, F, iters, early, ebn0, grids):
         its = d_it.float().max().item()
         print("%-24s F=%2d early=%d blocks<=%4d %-16s %8.3f ms  %6.1f us per iteration (max iters %d)" % (
             name, F, early, g, dec.last_decode_kernel(), best, best * 1e3 / its, its), flush=True)
-    os.environ.pop("LDPC_AMD_NODES_BLOCKS", None)
+    L.capi.set_default_options()
     dec.close()
 
 

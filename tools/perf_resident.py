@@ -16,7 +16,7 @@ def run(name, code, F, iters, early, ebn0):
     d_it = torch.empty(F, dtype=torch.int32, device="cuda")
     d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
     for wpe in ("4", "6"):
-        os.environ["LDPC_AMD_LDS_WPE"] = wpe
+        L.capi.set_default_options(lds_wpe=int(wpe))
         best = 1e30
         for _ in range(3):
             dec.decode_batch_dev(d_llr.data_ptr(), F, iters, early, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Row-parallel sweeps: waves per launch (LDPC_AMD_ROWS_WAVES) on the irregular BG1-sized code and the long regular code."""
+"""Row-parallel sweeps: waves per launch (option rows_waves) on the irregular BG1-sized code and the long regular code."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import ldpc_simulator_amd as L
+
+
+BASE = {}
 
 
 def run(name, code, F, iters, early, ebn0, settings):
@@ -16,7 +19,7 @@ def run(name, code, F, iters, early, ebn0, settings):
     d_it = torch.empty(F, dtype=torch.int32, device="cuda")
     d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
     for w in settings:
-        os.environ["LDPC_AMD_ROWS_WAVES"] = str(w)
+        L.capi.set_default_options(rows_waves=w, **BASE)
         best = 1e30
         for _ in range(2):
             dec.decode_batch_dev(d_llr.data_ptr(), F, iters, early, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
@@ -24,7 +27,7 @@ def run(name, code, F, iters, early, ebn0, settings):
         bytes_ = F * d_it.float().mean().item() * (4 * dec.E * 4 + n * 4)
         print("%-24s F=%6d early=%d waves=%6d %-16s %8.1f ms %7.3f Gbit/s  algorithmic %6.0f GB/s" % (
             name, F, early, w, dec.last_decode_kernel(), best, F * (n - m) / best / 1e6, bytes_ / best / 1e6), flush=True)
-    os.environ.pop("LDPC_AMD_ROWS_WAVES", None)
+    L.capi.set_default_options(**BASE)
     dec.close()
 
 
@@ -37,8 +40,7 @@ c5 = L.codes.regular_ldpc(64800, 3, 6, 1)
 run("C5 (3,6) n=64800", c5, 1 << 16, 20, False, 1.6, S)
 run("C5 (3,6) n=64800", c5, 64, 50, True, 1.6, S)
 run("C5 (3,6) n=64800", c5, 1, 50, True, 1.6, S)
-os.environ["LDPC_AMD_ENGINE"] = "stream"
-os.environ["LDPC_AMD_ROWS"] = "1"
+BASE = {"engine": "stream", "stream_kernel": 0}
 run("C2 (3,6) n=4096 rows", L.codes.regular_ldpc(4096, 3, 6, 1), 1 << 17, 50, False, 1.0, S)
 run("C2 (3,6) n=4096 rows", L.codes.regular_ldpc(4096, 3, 6, 1), 1 << 17, 50, True, 2.0, S)
 run("QC z=108 rows", L.codes.random_qc(108, 5, 10, 1)[1], 1 << 16, 50, True, 3.0, S)

@@ -23,11 +23,11 @@ names = {0: "complement", 1: "minsum", 2: "tanh"}
 res = {}
 for r in range(rounds):
     for rule, fpl, wps, skip, eng in variants:
-        os.environ["LDPC_AMD_ENGINE"] = eng
+        # eng: "stream" = the one-launch streaming kernel, anything else = the library's choice; the skip
+        # field of a variant is kept for the layout of old result files and must be 0
+        assert skip == "0", "the library no longer has a switch that skips sweeps"
         layout = wps
-        os.environ["LDPC_AMD_WPS"] = wps
-        os.environ["LDPC_AMD_SKIP"] = skip
-        os.environ["LDPC_AMD_FPL"] = fpl
+        L.capi.set_default_options(engine="stream" if eng == "stream" else "auto", stream_kernel=1, wps=int(wps), fpl=int(fpl))
         dec.set_cn_rule(int(rule))
         dec.decode_batch_dev(d_llr.data_ptr(), F, iters, False, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
         nl, ms, fr = dec.last_decode_timing()
