@@ -143,6 +143,7 @@ int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
 /* read-only */
 #define LDPC_AMD_OPT_NODES_REFUSALS 200      /* cooperative launches the runtime refused on this context */
 #define LDPC_AMD_OPT_NODES_LAST_HIP_ERROR 201 /* hipError_t of the last refusal (0 = none) */
+#define LDPC_AMD_OPT_NOALLOC_MAX_FRAMES 202  /* largest batch ldpc_amd_decode_batch_dev_noalloc takes for this code */
 
 #define LDPC_AMD_ENGINE_AUTO 0    /* frame-resident kernels where the code fits in LDS, else streaming */
 #define LDPC_AMD_ENGINE_GENERIC 1 /* as AUTO, but never the kernels specialised for (6,3) / (8,2) codes */
@@ -172,6 +173,28 @@ int ldpc_amd_decode_batch(ldpc_amd_ctx* ctx, const float* llr, int64_t frames, i
 int ldpc_amd_decode_batch_dev(ldpc_amd_ctx* ctx, const float* d_llr, int64_t frames, int32_t max_iters,
                               int32_t early_term, uint8_t* d_hard, int32_t* d_iters,
                               int32_t* d_syndrome_weight, void* stream);
+
+/*
+ * ldpc_amd_decode_batch_dev for callers that cannot allocate device memory while they decode: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
+ * reference (whose decode() allocates all of its state per call, LogDecoder.java:57-58).  Same arguments,
+ * same outputs bit for bit; it calls no hipMalloc / hipFree or other allocating routine.  The frame-major
+ * message, LLR, decision and per-frame state arrays of the sweep kernels ("rows_cn_kernel"), which the
+ * other entry points keep in a workspace they allocate, live in a static device array of
+ * LDPC_AMD_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
+ * Limits: the batch must fit into that array in one piece, (E + n + ceil(n/32) + 4) * 256 bytes per 64
+ * frames -- 1,984 frames of a (3,6) n = 4096 code, 192 of an NR-BG1-sized Z = 384 code, 128 of an
+ * n = 64800 (3,6) code (ldpc_amd_get_option(LDPC_AMD_OPT_NOALLOC_MAX_FRAMES) gives the number for the
+ * context's code); a larger batch fails with LDPC_AMD_ELIMIT and nothing is launched.  The engine options
+ * are not consulted (always the sweep launches, one frame per lane).  All calls on one GPU, from any
+ * context, share that GPU's array: calls that overlap in time on one GPU race, so the caller serialises
+ * them (one stream, or events between streams).  The array keeps the last call's contents; what must
+ * start at zero is cleared on the stream at the start of each call.
+ */
+#define LDPC_AMD_NOALLOC_SCRATCH_BYTES (128u << 20)
+int ldpc_amd_decode_batch_dev_noalloc(ldpc_amd_ctx* ctx, const float* d_llr, int64_t frames, int32_t max_iters,
+                                      int32_t early_term, uint8_t* d_hard, int32_t* d_iters,
+                                      int32_t* d_syndrome_weight, void* stream);
 
 /*
  * The reference's own calling convention: hard received words r[frames][n] (uint8, 0/1)

@@ -27,9 +27,9 @@ OPT = {
     "engine": 1, "stream_kernel": 2, "nodes": 3, "sim_overlap": 4, "verbose": 5,
     "lds_wpe": 100, "lds_fpw": 101, "generic_lds_kb": 102, "nodes_blocks": 103, "fpl": 104, "layout": 105,
     "rows_waves": 106, "wps": 107, "nopipe": 108, "test_nodes_oversize": 190,
-    "nodes_refusals": 200, "nodes_last_hip_error": 201,
+    "nodes_refusals": 200, "nodes_last_hip_error": 201, "noalloc_max_frames": 202,
 }
-OPT_READ_ONLY = ("nodes_refusals", "nodes_last_hip_error")
+OPT_READ_ONLY = ("nodes_refusals", "nodes_last_hip_error", "noalloc_max_frames")
 OPT_LIBRARY_DEFAULT = {"nodes": -1, "sim_overlap": 1}   # every other option defaults to 0
 ENGINE_AUTO, ENGINE_GENERIC, ENGINE_STREAM = 0, 1, 2
 ENGINES = {"auto": ENGINE_AUTO, "generic": ENGINE_GENERIC, "stream": ENGINE_STREAM}
@@ -69,6 +69,7 @@ SIGNATURES = {
     "ldpc_amd_last_warning": (C.c_char_p, [_vp]),
     "ldpc_amd_decode_batch": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "ldpc_amd_decode_batch_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ldpc_amd_decode_batch_dev_noalloc": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ldpc_amd_decode_bsc_batch": (C.c_int, [_vp, _vp, _i64, _f64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ldpc_amd_decode_bsc_batch_dev": (C.c_int, [_vp, _vp, _i64, _f64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ldpc_amd_set_generator": (C.c_int, [_vp, _i32, _vp]),
@@ -310,6 +311,13 @@ class Decoder:
         self._check(self._lib.ldpc_amd_decode_batch_dev(self._h, d_llr, int(frames), int(max_iters),
                                                         int(bool(early_term)), d_hard, d_iters or None,
                                                         d_synd or None, stream or None))
+
+    def decode_batch_dev_noalloc(self, d_llr, frames, max_iters, early_term, d_hard, d_iters=0, d_synd=0, stream=0):
+        """decode_batch_dev on the library's static device scratch array: allocates nothing, takes at most
+        get_option("noalloc_max_frames") frames."""
+        self._check(self._lib.ldpc_amd_decode_batch_dev_noalloc(self._h, d_llr, int(frames), int(max_iters),
+                                                                int(bool(early_term)), d_hard, d_iters or None,
+                                                                d_synd or None, stream or None))
 
     def decode_bsc_batch_dev(self, d_r, frames, e, llr_mode, max_iters, early_term, d_hard, d_iters=0, d_synd=0,
                              stream=0):

@@ -51,6 +51,7 @@ struct ldpc_amd_ctx {
     // decode workspace: [tiles][E][T] messages | [tiles][n][T] lambda | [tiles][nw][T] decisions
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    void* scratch_ptr = nullptr;  // this device's copy of the static scratch array (see g_scratch_ptr)
     unsigned long long ws_limit = 0;
     // staging for the host-pointer entry points and for simulate
     // (slots 4..7 are the second set of the double-buffered host-pointer path)
@@ -86,7 +87,17 @@ struct ldpc_amd_ctx {
     std::string warn;  // last event that did not fail a call (ldpc_amd_last_warning)
 };
 
+// Scratch memory of ldpc_amd_decode_batch_dev_noalloc: the frame-major message, LLR, decision and
+// per-frame state arrays of the sweep kernels, which every other entry point keeps in a hipMalloc'd
+// workspace.  One copy per GPU the library runs on, held until the process ends; host code reaches it only
+// through the address hipGetSymbolAddress returns for the current device (g_scratch_ptr), never by name.
+static __device__ __align__(256) unsigned char scratch[LDPC_AMD_NOALLOC_SCRATCH_BYTES];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices];  // [device] address of that device's copy of `scratch`, set by ldpc_amd_create
 
 std::mutex g_err_mutex;
 std::string g_create_err;
@@ -381,8 +392,9 @@ size_t stream_tile_bytes(const ldpc_amd_ctx* c, int T) {
     return ((size_t)c->E + (size_t)c->n + (size_t)c->nw + 4) * (size_t)T * sizeof(float);
 }
 
+// noalloc: run the sweep launches on the static scratch array and call nothing that allocates.
 int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_iters, int early_term, uint8_t* d_hard,
-               int32_t* d_iters, int32_t* d_synd, hipStream_t s) {
+               int32_t* d_iters, int32_t* d_synd, hipStream_t s, bool noalloc = false) {
     if (frames < 0 || max_iters < 0 || !d_hard) return fail(c, LDPC_AMD_EINVAL, "decode: bad argument");
     c->timed_launches = 0;
     c->timed_frames = 0;
@@ -396,7 +408,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     }
     const bool early = early_term != 0;
     // Frame-resident engine: regular code whose messages fit at least twice into a CU's LDS.
-    {
+    if (!noalloc) {
         const bool shape = (c->reg_dc == 6 && c->reg_dv == 3) || (c->reg_dc == 8 && c->reg_dv == 2);
         // exact tiling: 8 variables and 8 m / n checks per thread, whole wavefronts
         const int nt = n / kLdsVpt;
@@ -444,7 +456,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     }
     // Generic frame-resident engine: any code whose messages and LLRs fit into a CU's LDS and whose
     // degrees the register code covers.
-    {
+    if (!noalloc) {
         // about 8 variables per thread, whole wavefronts, at most 512 threads
         const int nt = std::min(512, std::max(64, ((std::max(n, c->m) + 7) / 8 + 63) / 64 * 64));
         bool use = c->m > 0 && c->max_dc <= kLdsGenMaxDc && c->max_dv <= kLdsGenMaxDv && frames <= 0x7fffffffll &&
@@ -501,7 +513,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     }
     // Node-parallel cooperative engine: a batch of at most 32 frames of a code the resident engines do
     // not take runs in one launch with one thread per node (a lane per frame would leave the chip empty).
-    {
+    if (!noalloc) {
         const bool can = frames <= kNodesMaxFrames && c->m > 0 && c->max_dc <= kNodesMaxDc && c->max_dv <= kNodesMaxDv &&
                          c->nodes_blocks >= 0 && c->opt.engine != LDPC_AMD_ENGINE_STREAM;
         bool use = can;
@@ -586,9 +598,9 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     }
     const int maxdeg = std::max(c->max_dc, c->max_dv);
     if (maxdeg > kLdsMaxDegree) return fail(c, LDPC_AMD_ELIMIT, "node degree above 128 is not supported");
-    int fpl = (!early && maxdeg <= kRegDegFpl4) ? 4 : 1;
+    int fpl = (!early && maxdeg <= kRegDegFpl4 && !noalloc) ? 4 : 1;
     if (const int v = c->opt.fpl) {
-        if (!early && maxdeg <= kRegDegFpl4 && (v == 1 || v == 2 || v == 4)) fpl = v;
+        if (!early && maxdeg <= kRegDegFpl4 && (v == 1 || v == 2 || v == 4) && !noalloc) fpl = v;
     }
     const int T = 64 * fpl;
     // rows above the kernels' register limit are staged through LDS, one wave per block
@@ -600,7 +612,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     const long long tiles_total = (frames + T - 1) / T;
     // + 4 words of per-frame state for the row-parallel launches
     const size_t per_tile = stream_tile_bytes(c, T);
-    unsigned long long limit = c->ws_limit;
+    unsigned long long limit = noalloc ? (unsigned long long)LDPC_AMD_NOALLOC_SCRATCH_BYTES : c->ws_limit;
     if (!limit) {
         size_t fr = 0, tot = 0;
         LDPC_HIP(c, hipMemGetInfo(&fr, &tot));
@@ -611,24 +623,39 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     if (max_tiles > (1ll << 30)) max_tiles = 1ll << 30;
     // layout 0: [tile][row][T]  (a tile's rows are contiguous)
     // layout 1: [row][tile][T]  (the same row of neighbouring tiles is contiguous)
-    const int layout = c->opt.layout ? 1 : 0;
+    const int layout = (c->opt.layout && !noalloc) ? 1 : 0;
     // Every sweep is its own launch over (tile, row chunk) pairs, cut as finely as the packed decision
     // words allow (32 variables per wave): short uniform waves walk through the tiles in address order,
     // a wave whose frames have all converged ends at once, and a batch of any size fills the chip.
     // LDPC_AMD_OPT_STREAM_KERNEL = 1 selects the other streaming kernel, one wave per tile for the whole decode.
-    const bool by_rows = layout == 0 && fpl != 2 && c->opt.stream_kernel == 0;
+    const bool by_rows = layout == 0 && fpl != 2 && (c->opt.stream_kernel == 0 || noalloc);
     if (by_rows) max_tiles = std::min<long long>(max_tiles, 65535);  // tiles are the grid's y dimension
     const long long rounds = (tiles_total + max_tiles - 1) / max_tiles;
     const long long tiles_per_round = (tiles_total + rounds - 1) / rounds;
     const size_t need = per_tile * (size_t)tiles_per_round;
-    if (c->ws_bytes < need) {
-        if (c->ws) {
-            LDPC_HIP(c, hipFree(c->ws));
-            c->ws = nullptr;
-            c->ws_bytes = 0;
+    void* ws = nullptr;
+    if (noalloc) {
+        // the whole batch in one round inside the fixed array, or not at all
+        if (rounds > 1 || need > (size_t)LDPC_AMD_NOALLOC_SCRATCH_BYTES || (long long)limit / (long long)per_tile < 1)
+            return fail(c, LDPC_AMD_ELIMIT,
+                        "decode_batch_dev_noalloc: " + std::to_string(frames) + " frames of this code need " +
+                            std::to_string(need * (size_t)rounds) + " bytes of scratch, the static array holds " +
+                            std::to_string((size_t)LDPC_AMD_NOALLOC_SCRATCH_BYTES) + " (at most " +
+                            std::to_string((long long)(LDPC_AMD_NOALLOC_SCRATCH_BYTES / per_tile) * T) + " frames per call)");
+        if (!c->scratch_ptr) return fail(c, LDPC_AMD_EHIP, "decode_batch_dev_noalloc: no scratch address for this device");
+        if (c->ev.size() < 2) return fail(c, LDPC_AMD_EHIP, "decode_batch_dev_noalloc: timing events missing");
+        ws = c->scratch_ptr;
+    } else {
+        if (c->ws_bytes < need) {
+            if (c->ws) {
+                LDPC_HIP(c, hipFree(c->ws));
+                c->ws = nullptr;
+                c->ws_bytes = 0;
+            }
+            LDPC_HIP(c, hipMalloc(&c->ws, need));
+            c->ws_bytes = need;
         }
-        LDPC_HIP(c, hipMalloc(&c->ws, need));
-        c->ws_bytes = need;
+        ws = c->ws;
     }
     c->last_kernel = "bp_decode_kernel";
     while ((long long)c->ev.size() < 2 * std::min<long long>(rounds, 256)) {
@@ -647,7 +674,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         p.msg_row = p.lam_row = p.bits_row = tiles_per_round * T;
         p.msg_tile = p.lam_tile = p.bits_tile = T;
     }
-    float* ws_msg = (float*)c->ws;
+    float* ws_msg = (float*)ws;
     float* ws_lam = ws_msg + (size_t)tiles_per_round * c->E * T;
     uint32_t* ws_bits = (uint32_t*)(ws_lam + (size_t)tiles_per_round * n * T);
     int32_t* ws_state = (int32_t*)(ws_bits + (size_t)tiles_per_round * c->nw * T);
@@ -854,6 +881,27 @@ int ldpc_amd_create(int32_t m, int32_t n, int64_t nnz, const int32_t* row_idx, c
         return code;
     };
     if (!guard.ok) return bail(LDPC_AMD_EHIP, "create: hipSetDevice failed");
+    // Address of this device's copy of the static scratch array, asked for once per device with that device
+    // current; and the two timing events of a one-round decode, so that ldpc_amd_decode_batch_dev_noalloc
+    // finds everything it needs in place.
+    if (dev >= kMaxDevices) return bail(LDPC_AMD_EINVAL, "create: device_id above the library's table of devices");
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {
+            void* ptr = nullptr;
+            const hipError_t se = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+            if (se != hipSuccess || !ptr)
+                return bail(LDPC_AMD_EHIP, std::string("create: hipGetSymbolAddress(scratch): ") + hipGetErrorString(se));
+            g_scratch_ptr[dev] = ptr;
+        }
+        c->scratch_ptr = g_scratch_ptr[dev];
+    }
+    for (int i = 0; i < 2; ++i) {
+        hipEvent_t ev;
+        const hipError_t ee = hipEventCreate(&ev);
+        if (ee != hipSuccess) return bail(LDPC_AMD_EHIP, std::string("create: hipEventCreate: ") + hipGetErrorString(ee));
+        c->ev.push_back(ev);
+    }
     const size_t eb = (size_t)std::max<long long>(c->E, 1) * sizeof(int);
     hipError_t e;
     if ((e = hipMalloc((void**)&c->d_row_ptr, ((size_t)m + 1) * sizeof(int))) != hipSuccess ||
@@ -951,6 +999,7 @@ int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: if (!range(0, 1)) break; o.test_nodes_oversize = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_NODES_REFUSALS:
         case LDPC_AMD_OPT_NODES_LAST_HIP_ERROR:
+        case LDPC_AMD_OPT_NOALLOC_MAX_FRAMES:
             return fail(c, LDPC_AMD_EINVAL, "set_option: key " + std::to_string(key) + " is read-only");
         default: return fail(c, LDPC_AMD_EINVAL, "set_option: unknown key " + std::to_string(key));
     }
@@ -978,6 +1027,9 @@ int ldpc_amd_get_option(const ldpc_amd_ctx* c, int32_t key, int64_t* value) {
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: *value = o.test_nodes_oversize; break;
         case LDPC_AMD_OPT_NODES_REFUSALS: *value = c->nodes_refusals; break;
         case LDPC_AMD_OPT_NODES_LAST_HIP_ERROR: *value = c->nodes_last_error; break;
+        case LDPC_AMD_OPT_NOALLOC_MAX_FRAMES:
+            *value = (int64_t)(LDPC_AMD_NOALLOC_SCRATCH_BYTES / stream_tile_bytes(c, 64)) * 64;
+            break;
         default: return LDPC_AMD_EINVAL;
     }
     return LDPC_AMD_OK;
@@ -993,6 +1045,17 @@ int ldpc_amd_decode_batch_dev(ldpc_amd_ctx* c, const float* d_llr, int64_t frame
     if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
     SrcArgs src{Src::Float, d_llr, nullptr, 0.0, 0.0};
     return decode_dev(c, src, frames, max_iters, early_term, d_hard, d_iters, d_synd, (hipStream_t)stream);
+}
+
+int ldpc_amd_decode_batch_dev_noalloc(ldpc_amd_ctx* c, const float* d_llr, int64_t frames, int32_t max_iters,
+                                      int32_t early_term, uint8_t* d_hard, int32_t* d_iters, int32_t* d_synd,
+                                      void* stream) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (!d_llr && frames > 0) return fail(c, LDPC_AMD_EINVAL, "decode_batch_dev_noalloc: llr is null");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    SrcArgs src{Src::Float, d_llr, nullptr, 0.0, 0.0};
+    return decode_dev(c, src, frames, max_iters, early_term, d_hard, d_iters, d_synd, (hipStream_t)stream, true);
 }
 
 int ldpc_amd_decode_bsc_batch_dev(ldpc_amd_ctx* c, const uint8_t* d_r, int64_t frames, double e, int32_t llr_mode,
