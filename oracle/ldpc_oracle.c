@@ -107,8 +107,52 @@ void oracle_graph_csc(const oracle_graph* g, int32_t* col_ptr, int32_t* col_edge
     memcpy(col_edge, g->col_edge, (size_t)g->E * sizeof(int32_t));
 }
 
+/* ---- sensitivity to the library functions' unspecified last bits ------------------------------
+ * The reference computes through java.lang.Math.tanh and Math.log (LogDecoder.java:10, :90), which
+ * the JDK specifies only to within 2.5 ulp and 1 ulp of the exact result; this file computes
+ * through the C library's.  To see whether any verdict depends on those bits, a decode can be
+ * run with every tanh and log result moved by a random whole number of ulps inside those bounds
+ * (|k| <= tanh_ulps, |k| <= log_ulps; 0 = off).  What the JDK does specify is kept: NaN, +-Inf and
+ * +-0 results are returned as they are, |tanh| never exceeds 1 and a tanh of exactly +-1 stays. */
+typedef struct {
+    int tanh_ulps, log_ulps;
+    uint64_t state;
+} ulp_noise;
+
+static inline uint64_t noise_next(ulp_noise* z) { /* xorshift64* */
+    uint64_t x = z->state;
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    z->state = x;
+    return x * 0x2545F4914F6CDD1DULL;
+}
+
+static inline double noise_move(ulp_noise* z, double v, int max_ulps) {
+    if (max_ulps <= 0 || v == 0.0 || isnan(v) || isinf(v)) return v;
+    /* k ulps up or down: neighbouring doubles of one sign are neighbouring integers in their bit patterns */
+    const int64_t k = (int64_t)(noise_next(z) % (uint64_t)(2 * (int64_t)max_ulps + 1)) - max_ulps;
+    int64_t bits;
+    memcpy(&bits, &v, sizeof bits);
+    const int64_t mag = (bits & INT64_MAX) + ((bits < 0) ? -k : k);
+    if (mag <= 0 || mag >= 0x7FF0000000000000LL) return v; /* would cross zero or leave the finite range */
+    bits = (bits & INT64_MIN) | mag;
+    memcpy(&v, &bits, sizeof bits);
+    return v;
+}
+
+static inline double ref_tanh(double x, ulp_noise* z) {
+    double t = tanh(x);
+    if (!z || z->tanh_ulps <= 0 || t == 1.0 || t == -1.0) return t;
+    t = noise_move(z, t, z->tanh_ulps);
+    return (t > 1.0) ? 1.0 : (t < -1.0) ? -1.0 : t;
+}
+
+static inline double ref_log(double x, ulp_noise* z) {
+    const double v = log(x);
+    return z ? noise_move(z, v, z->log_ulps) : v;
+}
+
 /* LogDecoder.java:9-11 */
-static inline double ref_atanh(double x) { return 0.5 * log((1.0 + x) / (1.0 - x)); }
+static inline double ref_atanh(double x, ulp_noise* z) { return 0.5 * ref_log((1.0 + x) / (1.0 - x), z); }
 
 /* Math.signum: 0 for +-0, NaN for NaN (MinSumDecoder.java:84) */
 static inline double ref_signum(double x) { return (x > 0.0) ? 1.0 : (x < 0.0) ? -1.0 : x; }
@@ -119,7 +163,7 @@ static inline double ref_signum(double x) { return (x > 0.0) ? 1.0 : (x < 0.0) ?
  * target edge instead of subtracting/dividing it out (LogDecoder.java:67-95). */
 static int decode_sparse(const oracle_graph* g, const double* lambda, int max_iters, int early_term,
                          int cn_rule, uint8_t* hard, int32_t* iters_out, int32_t* synd_out,
-                         double* alpha, double* beta, double* th) {
+                         double* alpha, double* beta, double* th, ulp_noise* nz) {
     const int m = g->m, n = g->n;
     const int64_t E = g->E;
     for (int64_t p = 0; p < E; p++) alpha[p] = 0.0; /* new double[numC][numV], :57 */
@@ -140,7 +184,7 @@ static int decode_sparse(const oracle_graph* g, const double* lambda, int max_it
         }
         /* check nodes, :82-95 (sum-product) or MinSumDecoder.java:76-94 */
         if (cn_rule == ORACLE_CN_SUMPRODUCT) {
-            for (int64_t p = 0; p < E; p++) th[p] = tanh(0.5 * beta[p]);
+            for (int64_t p = 0; p < E; p++) th[p] = ref_tanh(0.5 * beta[p], nz);
             for (int i = 0; i < m; i++) {
                 const int32_t a = g->row_ptr[i], b = g->row_ptr[i + 1];
                 for (int32_t x = a; x < b; x++) {
@@ -149,7 +193,7 @@ static int decode_sparse(const oracle_graph* g, const double* lambda, int max_it
                         if (y == x) continue;
                         prod *= th[y];
                     }
-                    alpha[x] = 2 * ref_atanh(prod);
+                    alpha[x] = 2 * ref_atanh(prod, nz);
                 }
             }
         } else {
@@ -201,7 +245,25 @@ int oracle_decode_llr(const oracle_graph* g, const double* llr, int max_iters, i
     double* th = (double*)malloc((size_t)E * sizeof(double));
     if (!alpha || !beta || !th) { free(alpha); free(beta); free(th); return -2; }
     int rc = decode_sparse(g, llr, max_iters, early_term, cn_rule, hard, iters, syndrome_weight,
-                           alpha, beta, th);
+                           alpha, beta, th, NULL);
+    if (alpha_out) memcpy(alpha_out, alpha, (size_t)g->E * sizeof(double));
+    if (beta_out) memcpy(beta_out, beta, (size_t)g->E * sizeof(double));
+    free(alpha); free(beta); free(th);
+    return rc;
+}
+
+int oracle_decode_llr_noisy(const oracle_graph* g, const double* llr, int max_iters, int early_term,
+                            int cn_rule, uint8_t* hard, int32_t* iters, int32_t* syndrome_weight,
+                            double* alpha_out, double* beta_out, int tanh_ulps, int log_ulps,
+                            uint64_t noise_seed) {
+    const int64_t E = g->E ? g->E : 1;
+    double* alpha = (double*)malloc((size_t)E * sizeof(double));
+    double* beta = (double*)calloc((size_t)E, sizeof(double));
+    double* th = (double*)malloc((size_t)E * sizeof(double));
+    if (!alpha || !beta || !th) { free(alpha); free(beta); free(th); return -2; }
+    ulp_noise nz = {tanh_ulps, log_ulps, noise_seed | 1ULL};
+    int rc = decode_sparse(g, llr, max_iters, early_term, cn_rule, hard, iters, syndrome_weight,
+                           alpha, beta, th, (tanh_ulps > 0 || log_ulps > 0) ? &nz : NULL);
     if (alpha_out) memcpy(alpha_out, alpha, (size_t)g->E * sizeof(double));
     if (beta_out) memcpy(beta_out, beta, (size_t)g->E * sizeof(double));
     free(alpha); free(beta); free(th);
@@ -237,10 +299,42 @@ int oracle_decode_llr_batch_f32(const oracle_graph* g, const float* llr, int64_t
             for (int64_t f = 0; f < frames; f++) {
                 for (int j = 0; j < n; j++) lam[j] = (double)llr[f * n + j];
                 decode_sparse(g, lam, max_iters, early_term, cn_rule, hard + f * n, iters + f,
-                              syndrome_weight + f, alpha, beta, th);
+                              syndrome_weight + f, alpha, beta, th, NULL);
             }
         }
         free(alpha); free(beta); free(th); free(lam);
+    }
+    return fail ? -2 : 0;
+}
+
+int oracle_decode_llr_batch_f64(const oracle_graph* g, const double* llr, int64_t frames,
+                                int max_iters, int early_term, int cn_rule, uint8_t* hard,
+                                int32_t* iters, int32_t* syndrome_weight, int threads,
+                                int tanh_ulps, int log_ulps, uint64_t noise_seed) {
+    const int n = g->n;
+    const int64_t E = g->E ? g->E : 1;
+    int fail = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        double* alpha = (double*)malloc((size_t)E * sizeof(double));
+        double* beta = (double*)calloc((size_t)E, sizeof(double));
+        double* th = (double*)malloc((size_t)E * sizeof(double));
+        if (!alpha || !beta || !th) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+#pragma omp for schedule(dynamic, 4)
+            for (int64_t f = 0; f < frames; f++) {
+                /* the noise of a frame depends on (seed, frame) only, not on the thread that decodes it */
+                ulp_noise nz = {tanh_ulps, log_ulps,
+                                (noise_seed + 0x9E3779B97F4A7C15ULL * (uint64_t)(f + 1)) | 1ULL};
+                const int on = tanh_ulps > 0 || log_ulps > 0;
+                decode_sparse(g, llr + f * n, max_iters, early_term, cn_rule, hard + f * n, iters + f,
+                              syndrome_weight + f, alpha, beta, th, on ? &nz : NULL);
+            }
+        }
+        free(alpha); free(beta); free(th);
     }
     return fail ? -2 : 0;
 }
@@ -321,9 +415,9 @@ int oracle_logdecoder_dense(const int32_t* H, int m, int n, const int32_t* r, do
                     for (int32_t y = Acnt[i]; y < Acnt[i + 1]; y++) {
                         const int k = A[y];
                         if (k == j) continue;
-                        product *= tanh(0.5 * beta[(size_t)k * numC + i]);
+                        product *= ref_tanh(0.5 * beta[(size_t)k * numC + i], NULL);
                     }
-                    alpha[(size_t)i * numV + j] = 2 * ref_atanh(product);
+                    alpha[(size_t)i * numV + j] = 2 * ref_atanh(product, NULL);
                 } else {
                     for (int32_t y = Acnt[i]; y < Acnt[i + 1]; y++) {
                         const int k = A[y];
@@ -522,7 +616,7 @@ int oracle_simulate(const oracle_graph* g, int gen_k, const uint8_t* G, int chan
     uint8_t* hard = (uint8_t*)malloc((size_t)chunk * n);
     uint8_t* cw = G ? (uint8_t*)malloc((size_t)chunk * n) : NULL;
     float* llr = (float*)malloc((size_t)chunk * n * sizeof(float));
-    double* tmp = (double*)malloc((size_t)(n ? n : 1) * sizeof(double));
+    double* tmp = (double*)malloc((size_t)chunk * (n ? n : 1) * sizeof(double));
     int32_t* it = (int32_t*)malloc((size_t)chunk * sizeof(int32_t));
     int32_t* sw = (int32_t*)malloc((size_t)chunk * sizeof(int32_t));
     if (!r || !hard || (G && !cw) || !llr || !tmp || !it || !sw) return -2;
@@ -538,13 +632,13 @@ int oracle_simulate(const oracle_graph* g, int gen_k, const uint8_t* G, int chan
             /* LogDecoder.java:47 / MinSumDecoder.java:41: the parity constant goes with the decoder class */
             const int pmode = (cn_rule == ORACLE_CN_MINSUM) ? ORACLE_LLR_PARITY_1EM7 : ORACLE_LLR_PARITY_LN1E20;
             const int mode = (channel == ORACLE_CH_BSC_INFO) ? pmode : ORACLE_LLR_UNIFORM;
-            for (int64_t f = 0; f < nf; f++) {
-                oracle_bsc_llr(m, n, r + f * n, param, mode, tmp);
-                /* the device path stores channel LLRs as float */
-                for (int j = 0; j < n; j++) llr[f * n + j] = (float)tmp[j];
-            }
+            /* lambda stays double, as in the reference (LogDecoder.java:45-54) */
+            for (int64_t f = 0; f < nf; f++) oracle_bsc_llr(m, n, r + f * n, param, mode, tmp + f * n);
         }
-        rc = oracle_decode_llr_batch_f32(g, llr, nf, max_iters, early_term, cn_rule, hard, it, sw, threads);
+        if (channel == ORACLE_CH_AWGN)
+            rc = oracle_decode_llr_batch_f32(g, llr, nf, max_iters, early_term, cn_rule, hard, it, sw, threads);
+        else
+            rc = oracle_decode_llr_batch_f64(g, tmp, nf, max_iters, early_term, cn_rule, hard, it, sw, threads, 0, 0, 0);
         if (rc == 0) oracle_count_errors(m, n, nf, hard, cw, r, it, sw, max_iters, counters);
     }
     free(r); free(hard); free(cw); free(llr); free(tmp); free(it); free(sw);

@@ -58,6 +58,22 @@ int oracle_decode_llr_batch_f32(const oracle_graph* g, const float* llr, int64_t
                                 int max_iters, int early_term, int cn_rule, uint8_t* hard,
                                 int32_t* iters, int32_t* syndrome_weight, int threads);
 
+/* Frame batch from double LLRs: what the reference itself decodes from in its BSC modes (lambda is a
+ * double[] there, LogDecoder.java:45-54).  tanh_ulps / log_ulps > 0 move every tanh / log result by a
+ * random whole number of ulps of at most that size (seeded per frame by noise_seed): the JDK specifies
+ * Math.tanh only to 2.5 ulp and Math.log to 1 ulp, and the tests use this to count the frames whose
+ * result depends on those unspecified bits.  0, 0 is the plain decode. */
+int oracle_decode_llr_batch_f64(const oracle_graph* g, const double* llr, int64_t frames,
+                                int max_iters, int early_term, int cn_rule, uint8_t* hard,
+                                int32_t* iters, int32_t* syndrome_weight, int threads,
+                                int tanh_ulps, int log_ulps, uint64_t noise_seed);
+
+/* One frame with that noise, messages out: lets a test see that the noise reaches the messages. */
+int oracle_decode_llr_noisy(const oracle_graph* g, const double* llr, int max_iters, int early_term,
+                            int cn_rule, uint8_t* hard, int32_t* iters, int32_t* syndrome_weight,
+                            double* alpha_out, double* beta_out, int tanh_ulps, int log_ulps,
+                            uint64_t noise_seed);
+
 /* lambda from a hard received word, LogDecoder.java:45-54 and variants. */
 void oracle_bsc_llr(int m, int n, const uint8_t* r, double e, int llr_mode, double* llr);
 

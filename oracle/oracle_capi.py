@@ -37,6 +37,8 @@ def _load():
     lib.oracle_graph_csc.argtypes = [vp, vp, vp]
     lib.oracle_decode_llr.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.oracle_decode_llr_batch_f32.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, i32]
+    lib.oracle_decode_llr_batch_f64.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, i32, i32, i32, u64]
+    lib.oracle_decode_llr_noisy.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, u64]
     lib.oracle_bsc_llr.argtypes = [i32, i32, vp, f64, i32, vp]
     lib.oracle_logdecoder_dense.argtypes = [vp, i32, i32, vp, f64, i32, i32, i32, vp, vp, vp]
     lib.oracle_logdecoder_dense_batch.argtypes = [vp, i32, i32, vp, i64, f64, i32, i32, vp, vp, vp, i32]
@@ -116,6 +118,21 @@ class Graph:
             return hard, it.value, sw.value, al[: self.E], be[: self.E]
         return hard, it.value, sw.value
 
+    def decode_llr_noisy(self, llr, max_iters, early_term, tanh_ulps, log_ulps, noise_seed, cn_rule=CN_SUMPRODUCT):
+        """One frame with every tanh / log result moved by up to that many ulps; returns (hard, iters, synd, alpha, beta)."""
+        llr = np.ascontiguousarray(llr, dtype=np.float64)
+        assert llr.shape == (self.n,)
+        hard = np.zeros(self.n, np.uint8)
+        it, sw = C.c_int(0), C.c_int(0)
+        al = np.zeros(max(self.E, 1))
+        be = np.zeros(max(self.E, 1))
+        rc = lib().oracle_decode_llr_noisy(self._h, _p(llr), int(max_iters), int(bool(early_term)), int(cn_rule),
+                                           _p(hard), C.byref(it), C.byref(sw), _p(al), _p(be), int(tanh_ulps),
+                                           int(log_ulps), int(noise_seed))
+        if rc != 0:
+            raise RuntimeError("oracle_decode_llr_noisy failed: %d" % rc)
+        return hard, it.value, sw.value, al[: self.E], be[: self.E]
+
     def decode_llr_batch(self, llr, max_iters, early_term=True, cn_rule=CN_SUMPRODUCT, threads=None):
         llr = np.ascontiguousarray(llr, dtype=np.float32)
         frames = llr.shape[0]
@@ -128,6 +145,24 @@ class Graph:
                                                int(threads or max_threads()))
         if rc != 0:
             raise RuntimeError("oracle_decode_llr_batch_f32 failed: %d" % rc)
+        return hard, it, sw
+
+    def decode_llr_batch_f64(self, llr, max_iters, early_term=True, cn_rule=CN_SUMPRODUCT, threads=None,
+                             tanh_ulps=0, log_ulps=0, noise_seed=0):
+        """Batch from double LLRs (the reference's own lambda in its BSC modes, LogDecoder.java:45-54).
+        tanh_ulps / log_ulps > 0: every tanh / log result is moved by a random whole number of ulps of at
+        most that size (the JDK bounds Math.tanh by 2.5 ulp and Math.log by 1 ulp)."""
+        llr = np.ascontiguousarray(llr, dtype=np.float64)
+        frames = llr.shape[0]
+        assert llr.shape == (frames, self.n)
+        hard = np.zeros((frames, self.n), np.uint8)
+        it = np.zeros(frames, np.int32)
+        sw = np.zeros(frames, np.int32)
+        rc = lib().oracle_decode_llr_batch_f64(self._h, _p(llr), frames, int(max_iters), int(bool(early_term)),
+                                               int(cn_rule), _p(hard), _p(it), _p(sw), int(threads or max_threads()),
+                                               int(tanh_ulps), int(log_ulps), int(noise_seed))
+        if rc != 0:
+            raise RuntimeError("oracle_decode_llr_batch_f64 failed: %d" % rc)
         return hard, it, sw
 
     def simulate(self, channel, param, seed, first_frame, frames, max_iters, early_term=True,
@@ -150,6 +185,12 @@ def bsc_llr(m, n, r, e, llr_mode):
     out = np.zeros(n, np.float64)
     lib().oracle_bsc_llr(int(m), int(n), _p(r), float(e), int(llr_mode), _p(out))
     return out
+
+
+def bsc_llr_batch(m, n, r, e, llr_mode):
+    """double lambda of every frame of r [frames][n], as the reference forms it (LogDecoder.java:45-54)"""
+    r = np.ascontiguousarray(r, dtype=np.uint8)
+    return np.stack([bsc_llr(m, n, r[f], e, llr_mode) for f in range(r.shape[0])]) if r.shape[0] else np.zeros((0, n))
 
 
 def logdecoder_dense(H, r, e, max_iters, llr_mode=LLR_PARITY_LN1E20, cn_rule=CN_SUMPRODUCT):
