@@ -25,6 +25,32 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
+# Ceilings of the frame-resident kernel, whose messages never leave the CU.  Unit of work: one edge-iteration
+# = one message through a check-node and a variable-node update.
+SIMDS = 256 * 4            # compute units x SIMD-32 units
+CLOCK_HZ = 2.4e9           # maximum shader clock; under this load the chip holds less, so fractions of these
+                           # ceilings are lower bounds
+# Vector-issue cycles one SIMD needs for 64 edge-iterations (one per lane), at the least:
+#   4 transcendentals per edge (2^|beta|, the reciprocal that gives q, 1/Q, log2), each an instruction of its
+#   own at 8 issue cycles;
+#   12 plain fp32 operations per edge, two edges to a packed instruction (v_pk_*) of 4 issue cycles.  Check
+#   node: scaling of 2^|beta| (1), fma to the denominator of q (1), prefix step 1 - Q and fma (2), suffix
+#   step likewise (2), fma joining prefix and suffix (1), fma(1/Q, 2, -1) (1), product of all signs, own
+#   sign out of it, sign onto the magnitude (3); variable node: prefix add, suffix add, their sum (3); that is
+#   14, of which the first prefix step and the last suffix step of a node are not needed: 12 on average.
+VALU_FLOOR_CYCLES_PER_64_EDGE_ITERS = 4 * 8 + (12 / 2) * 4
+# LDS cycles of one CU per edge-iteration at the data-path rates of the access shapes used: check side
+# ds_read_b128 (256 B/clk) and ds_write_b128 (79 B/clk), variable side ds_read_b32 (128 B/clk) and
+# ds_write_b32 (64 B/clk), 4 bytes each
+LDS_FLOOR_CYCLES_PER_EDGE_ITER = 4 / 256 + 4 / 79 + 4 / 128 + 4 / 64
+
+
+def resident_ceilings():
+    """edge-iterations per second the whole chip could issue / move through LDS at the maximum clock"""
+    valu = SIMDS * CLOCK_HZ * 64 / VALU_FLOOR_CYCLES_PER_64_EDGE_ITERS
+    lds = 256 * CLOCK_HZ / LDS_FLOOR_CYCLES_PER_EDGE_ITER
+    return valu, lds
+
 
 def algorithmic_bytes_per_frame(n, edges, iters, msg_bytes=4):
     """4*E*s + n*s per iteration: the CN sweep reads and writes E messages, the VN sweep reads
@@ -104,10 +130,11 @@ def measured_traffic(kernel_prefix, frames, iters, n):
 
 
 def measured_issue_rates(kernel_prefix):
-    """VALU and LDS busy fractions of the kernel from the committed SQ counter summary
+    """VALU and LDS busy fractions of the kernel from the newest committed SQ counter summary
     (profiles/<round>/*_sq_counters_*.txt, collected by tools/pmc_lds.sh): SQ_ACTIVE_INST_VALU counts
     4-cycle units per SIMD (1024 SIMDs), SQ_LDS_IDX_ACTIVE LDS cycles per CU (256), GRBM_GUI_ACTIVE is
-    summed over the 8 XCDs."""
+    summed over the 8 XCDs.  These describe the build and workload that file was collected on (its path is
+    returned as `source`), not this run."""
     import glob
     import re
     out = None
@@ -127,7 +154,43 @@ def measured_issue_rates(kernel_prefix):
     return out
 
 
-def main():
+class _PlumbingDecoder:
+    """Stand-in for ldpc_simulator_amd.Decoder on CPU tensors, used only by `--plumbing-test` (a world_size-2
+    gloo rehearsal of this file's stepping, all-reduce, timing and reporting without a GPU).  It decodes
+    nothing: every frame "decodes" to the all-zero word in max_iters iterations, and frame f of the global
+    numbering counts as a frame error when f % 7 == 0, so the all-reduced counters are known in closed form."""
+
+    E = 12288
+
+    def __init__(self, m, n, first_frame):
+        self.m, self.n, self.first = m, n, first_frame
+
+    def set_option(self, *a):
+        pass
+
+    def gen_awgn_llr_dev(self, *a):
+        pass
+
+    def decode_batch_dev(self, d_llr, F, iters, early, d_hard, d_it, d_sw, stream):
+        time.sleep(0.01 * (1 + self.first % 3))          # ranks take different times
+
+    def count_errors_dev(self, F, d_hard, d_rx, d_it, d_sw, iters, d_cnt, stream):
+        f = self.first + np.arange(F)
+        d_cnt[0] += F
+        d_cnt[1] += int((f % 7 == 0).sum())
+        d_cnt[CNT_FIXED_PLUMBING + iters - 1] += F
+
+    def last_decode_timing(self):
+        return 1, 10.0 * (1 + self.first % 3), 0
+
+    def last_decode_kernel(self):
+        return "plumbing-test"
+
+
+CNT_FIXED_PLUMBING = 16
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -141,7 +204,11 @@ def main():
                     help="auto: frame-resident kernel when the code fits in LDS; stream: force the frame-major HBM kernel")
     ap.add_argument("--no-stream-leg", action="store_true",
                     help="skip the extra single-step measurement of the streaming engine (N=1 only)")
-    args = ap.parse_args()
+    ap.add_argument("--plumbing-test", action="store_true",
+                    help="no GPU: gloo backend, CPU tensors and a stand-in decoder; rehearses the stepping, the "
+                         "all-reduce, the timing over ranks and the JSON line (tests/test_abi_and_host.py)")
+    args = ap.parse_args(argv)
+    plumbing = args.plumbing_test
 
     # Only the JSON line may appear on stdout: libraries underneath (RCCL prints a version banner at
     # init) write there too, so everything else goes to stderr while the run lasts.
@@ -159,40 +226,65 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if plumbing:
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
     # LDPC_BENCH_FORCE_DIST=1 initialises the process group also for a single rank (to rehearse the RCCL path)
     use_dist = world > 1 or (os.environ.get("LDPC_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if plumbing:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import ldpc_simulator_amd as L
 
-    code = L.codes.regular_ldpc(args.n, 3, 6, seed=1)
-    m, n, rows, cols = code
-    dec = L.Decoder(m, n, rows, cols, device=local_rank)
-    if args.engine == "stream":
-        dec.set_option("engine", "stream")
     F, iters = args.frames, args.iters
-    stream = torch.cuda.current_stream().cuda_stream
+    if plumbing:
+        m, n = args.n // 2, args.n
+        code = None
+        dec = _PlumbingDecoder(m, n, rank * F)
+        stream = 0
+    else:
+        code = L.codes.regular_ldpc(args.n, 3, 6, seed=1)
+        m, n, rows, cols = code
+        dec = L.Decoder(m, n, rows, cols, device=local_rank)
+        if args.engine == "stream":
+            dec.set_option("engine", "stream")
+        stream = torch.cuda.current_stream().cuda_stream
 
-    d_llr = torch.empty((F, n), dtype=torch.float32, device=dev)
+    def buf(shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=dev) if not plumbing else torch.empty((1,), dtype=dtype)
+
+    d_llr = buf((F, n), torch.float32)
     dec.gen_awgn_llr_dev(args.ebn0, 0x5EED, rank * F, F, d_llr.data_ptr(), stream)  # global frame index
-    d_hard = torch.empty((F, n), dtype=torch.uint8, device=dev)
-    d_it = torch.empty(F, dtype=torch.int32, device=dev)
-    d_sw = torch.empty(F, dtype=torch.int32, device=dev)
+    d_hard = buf((F, n), torch.uint8)
+    d_it = buf(F, torch.int32)
+    d_sw = buf(F, torch.int32)
     d_cnt = torch.zeros(L.capi.CNT_FIXED + iters, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
+    sync()
 
     kernel_ms, kernel_launches = 0.0, 0
+    allreduce_s = 0.0      # host-side time of this rank in the counter all-reduce, its wait for the slowest rank included
 
     def step(timed):
-        nonlocal kernel_ms, kernel_launches
+        nonlocal kernel_ms, kernel_launches, allreduce_s
         d_cnt.zero_()
         dec.decode_batch_dev(d_llr.data_ptr(), F, iters, False, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr(), stream)
-        dec.count_errors_dev(F, d_hard.data_ptr(), 0, d_it.data_ptr(), d_sw.data_ptr(), iters, d_cnt.data_ptr(), stream)
+        dec.count_errors_dev(F, d_hard.data_ptr(), 0, d_it.data_ptr(), d_sw.data_ptr(), iters,
+                             d_cnt if plumbing else d_cnt.data_ptr(), stream)
         if use_dist:
+            if timed:
+                sync()                      # the decode is over: what follows is the exchange alone
+                ta = time.perf_counter()
             dist.all_reduce(d_cnt)  # the only exchange: error counters (RCCL)
+            if timed:
+                sync()
+                allreduce_s += time.perf_counter() - ta
         if timed:
             nl, ms, _ = dec.last_decode_timing()  # HIP events on `stream` around the message-passing kernel
             kernel_ms += ms
@@ -202,18 +294,25 @@ def main():
         step(False)
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    dt_own_work = time.perf_counter() - t0 - allreduce_s   # this rank's steps without the exchange and its waiting
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    sync()
+    dt_rank = time.perf_counter() - t0
+    dt = dt_rank
+    per_rank = [[dt_rank, dt_own_work, allreduce_s]]
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt_rank], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = torch.tensor([dt_rank, dt_own_work, allreduce_s], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [[float(x) for x in e.cpu()] for e in every]
 
     kernel = dec.last_decode_kernel()
     cnt = d_cnt.cpu().numpy()
@@ -223,7 +322,38 @@ def main():
     b_frame = algorithmic_bytes_per_frame(n, dec.E, iters)
     frames_per_launch = F * args.steps / max(kernel_launches, 1)
     launch_s = kernel_ms / 1e3 / max(kernel_launches, 1)
-    achieved = frames_per_launch * b_frame / launch_s / 1e9 if launch_s > 0 else 0.0
+    hbm_achieved = frames_per_launch * b_frame / launch_s / 1e9 if launch_s > 0 else 0.0
+    hbm_equivalent = {
+        "bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_launch": frames_per_launch * b_frame,
+    }
+    if kernel == "bp_lds_kernel":
+        # The messages of a frame stay in the LDS of one CU for all iterations: the algorithmic message bytes
+        # never travel, so the HBM figure is an equivalent, not a fraction of a ceiling.  What bounds this
+        # kernel is vector instruction issue; the LDS data path is the next ceiling.
+        valu_peak, lds_peak = resident_ceilings()
+        edge_iters = frames_per_launch * dec.E * iters / launch_s if launch_s > 0 else 0.0
+        hbm_equivalent["note"] = ("algorithmic message bytes / time; they stay in LDS, so this exceeds the HBM peak "
+                                  "and `traffic` (measured HBM bytes per launch) is far below it")
+        roofline = {
+            "bound": "valu_issue", "achieved": edge_iters / 1e12, "peak": valu_peak / 1e12, "unit": "Tedge-iterations/s",
+            "frac": edge_iters / valu_peak,
+            "peak_definition": "1024 SIMDs x 2.4 GHz x 64 lanes / %.0f issue cycles per 64 edge-iterations "
+                               "(4 transcendentals x 8 cycles + 12 fp32 operations in 6 packed instructions x 4 cycles)"
+                               % VALU_FLOOR_CYCLES_PER_64_EDGE_ITERS,
+            "lds_ceiling": {"peak": lds_peak / 1e12, "unit": "Tedge-iterations/s", "frac": edge_iters / lds_peak,
+                            "peak_definition": "256 CUs x 2.4 GHz / %.3f LDS cycles per edge-iteration (b128 read and "
+                                               "write on the check side, b32 read and write on the variable side)"
+                                               % LDS_FLOOR_CYCLES_PER_EDGE_ITER},
+            "traffic": measured_traffic(kernel, F, iters, n),
+            "kernel": kernel, "launch_ms": launch_s * 1e3,
+            "edge_iterations_per_launch": frames_per_launch * dec.E * iters,
+            "hbm_equivalent": hbm_equivalent,
+            "issue_from_committed_profile": measured_issue_rates(kernel),
+        }
+    else:
+        roofline = dict(hbm_equivalent, traffic=measured_traffic(kernel, F, iters, n), kernel=kernel,
+                        launch_ms=launch_s * 1e3, note="frame-major streaming kernel: HBM-bound")
 
     out = {
         "metric": "decoded info Gbit/s at fixed iters",
@@ -237,7 +367,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not plumbing else "plumbing-test (no decoding)",
         "config": {
             "workload": "regular (3,6) n=%d rate-1/2, %d flooding sum-product iterations (early exit off), "
                         "%d frames per GPU per step, BPSK/AWGN Eb/N0=%.1f dB LLRs generated on device (Philox4x32-10), "
@@ -245,23 +375,14 @@ def main():
             "frames_per_gpu": F, "iterations": iters, "n": n, "m": m, "edges": int(dec.E),
             "parallelism": "frames sharded, %d rank(s), counters all-reduced" % world,
         },
-        "roofline": {
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": measured_traffic(kernel, F, iters, n),
-            "kernel": kernel,
-            "note": ("frame-resident kernel: messages stay in LDS, so `achieved` (algorithmic message bytes / time) "
-                     "exceeds what HBM could deliver and `traffic` (measured HBM bytes) is far below it; the kernel is "
-                     "bound by VALU issue (see the issue field)" if kernel == "bp_lds_kernel" else
-                     "frame-major streaming kernel: HBM-bound"),
-            "launch_ms": launch_s * 1e3,
-            "algorithmic_bytes_per_launch": frames_per_launch * b_frame,
-            "issue": measured_issue_rates(kernel) if kernel == "bp_lds_kernel" else None,
-        },
+        "roofline": roofline,
         "frame_error_rate": float(cnt[1]) / max(float(cnt[0]), 1.0),
+        # per rank: wall time of the timed steps, the part spent in its own decode and accounting, and the part
+        # spent in the counter all-reduce (which includes waiting for the slowest rank)
+        "per_rank": {"ms_per_step": [r[0] / args.steps * 1e3 for r in per_rank],
+                     "own_work_ms_per_step": [r[1] / args.steps * 1e3 for r in per_rank],
+                     "allreduce_ms_per_step": [r[2] / args.steps * 1e3 for r in per_rank]},
+        "counters": {"frames": int(cnt[0]), "frame_errors": int(cnt[1])},
     }
     if world == 1 and kernel == "bp_lds_kernel" and not args.no_stream_leg:
         # the same batch once through the frame-major HBM streaming engine, for the HBM roofline figure
@@ -284,7 +405,7 @@ def main():
                          "kernel": dec.last_decode_kernel(), "launch_ms": ms / max(nl, 1)},
         }
     if rank == 0:
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and not plumbing:
             out["cpu_baseline"] = cpu_baseline(code, args.ebn0, iters, args.cpu_seconds)
             out["cpu_baseline_dense"] = cpu_baseline_dense(code, iters, out["cpu_baseline"]["cores"])
         else:

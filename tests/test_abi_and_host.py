@@ -181,6 +181,44 @@ def test_world_size_two_gloo(tmp_path):
         assert p.returncode == 0, out
 
 
+def test_bench_plumbing_world_size_two_gloo():
+    """bench.py's own stepping, counter all-reduce, max-over-ranks timing and JSON line with two ranks on gloo
+    and a stand-in decoder (--plumbing-test), so that the first real multi-GPU run cannot fail on plumbing."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    F, steps = 1000, 2
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps),
+                                       "--warmup", "1", "--frames", str(F), "--plumbing-test"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err
+        outs.append(out)
+    assert outs[1].strip() == ""                      # only rank 0 prints
+    lines = [l for l in outs[0].splitlines() if l.strip()]
+    assert len(lines) == 1                            # exactly one line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == steps and d["scaling"] == "weak" and d["unit"] == "Gbit/s"
+    # whole-job value = frames of both ranks x k / the slowest rank's time
+    k = d["config"]["n"] - d["config"]["m"]
+    assert abs(d["value"] - 2 * F * steps * k / (d["ms_per_step"] * steps / 1e3) / 1e9) < 1e-9 * max(1.0, d["value"])
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and len(pr["allreduce_ms_per_step"]) == 2
+    assert d["ms_per_step"] >= max(pr["ms_per_step"]) - 1e-6       # the maximum over the ranks
+    # rank 1's stand-in decode sleeps twice as long: rank 0 waits for it inside the all-reduce
+    assert pr["own_work_ms_per_step"][1] > pr["own_work_ms_per_step"][0]
+    assert pr["allreduce_ms_per_step"][0] > pr["allreduce_ms_per_step"][1]
+    # counters of the last step, summed over both ranks: global frames 0 .. 2F-1, every 7th a frame error
+    assert d["counters"]["frames"] == 2 * F and d["counters"]["frame_errors"] == len(range(0, 2 * F, 7))
+
+
 def test_rates_from_counters(pkg):
     c = np.zeros(16 + 5, np.uint64)
     c[0], c[1], c[2], c[4], c[8], c[9], c[10] = 100, 4, 12, 3, 300, 20, 50

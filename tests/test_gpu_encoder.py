@@ -98,11 +98,14 @@ def test_simulate_with_generator(sys_code, oracle):
         rand = dec.simulate(ch, e, seed=3, first_frame=10, frames=3000, max_iters=40)
         assert 0 < zero[1] < 3000 and (zero == rand).all(), (zero[:12], rand[:12])
         want = g.simulate(ch, e, seed=3, first_frame=10, frames=3000, max_iters=40, G=c["eg"])
-        assert rand[10] == want[10] and rand[11] == want[11]
-        assert abs(int(rand[1]) - int(want[1])) <= 2 and abs(int(rand[8]) - int(want[8])) <= 90, (rand[:12], want[:12])
+        # every counter, histogram included: 3,000 frames leave no room for a differing frame at the 99.99 % bar
+        assert (rand == want).all(), (rand[:12], want[:12], np.nonzero(rand != want)[0])
     rand = dec.simulate(oracle.CH_AWGN, 3.5, seed=3, first_frame=0, frames=3000, max_iters=40)
     want = g.simulate(oracle.CH_AWGN, 3.5, seed=3, first_frame=0, frames=3000, max_iters=40, G=c["eg"])
-    assert abs(int(rand[10]) - int(want[10])) <= 2 and abs(int(rand[1]) - int(want[1])) <= 2, (rand[:12], want[:12])
+    # AWGN: the channel LLRs come from the device's logf/sinf/cosf and the C library's (ulps apart), so a
+    # received sign within an ulp of zero may differ: the channel-error counter may differ by that much, the
+    # decoded words may not
+    assert abs(int(rand[10]) - int(want[10])) <= 2 and (rand[:10] == want[:10]).all(), (rand[:12], want[:12])
     dec.set_generator(None)
 
 

@@ -1,0 +1,111 @@
+// Issue rates of the vector instructions the check-node rule is made of, on MI355X (gfx950): SIMD cycles
+// per wave64 instruction at 1 .. 8 waves per SIMD, every CU busy.  These set the VALU-issue ceiling of the
+// frame-resident decoder kernel (bench.py).
+// Build: hipcc -O3 --offload-arch=gfx950 -o tools/valu_rates tools/valu_rates.hip
+// Each wave runs REPS x 16 independent instructions of one kind (16 registers, each instruction depends only
+// on the one 16 earlier) between two s_memtime stamps; a workgroup is 4 waves (one per SIMD), k workgroups
+// per CU give k waves per SIMD.  Reported: median over waves of (cycles between the stamps) / (instructions
+// of one wave) = cycles of wave lifetime per instruction; divided by the k waves that share the SIMD that is
+// the SIMD's cycles per instruction when the waves overlap perfectly.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int REPS = 2048;
+
+enum Op { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, LOG, BFI, MIX };
+
+template <int OP>
+__global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, float* sink, float seed) {
+    float x[16];
+    v2f y[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { x[i] = seed + 0.001f * (threadIdx.x + i); y[i] = v2f{x[i], x[i] + 0.5f}; }
+    const float c1 = 0.999f, c2 = 0.0001f;
+    const v2f p1 = v2f{0.999f, 0.998f}, p2 = v2f{0.0001f, 0.0002f};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < REPS; ++r) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if constexpr (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(c1), "v"(c2));
+            if constexpr (OP == PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(y[i]) : "v"(p1), "v"(p2));
+            if constexpr (OP == PK_MUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[i]) : "v"(p1));
+            if constexpr (OP == PK_ADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y[i]) : "v"(p2));
+            if constexpr (OP == EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+            if constexpr (OP == RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]));
+            if constexpr (OP == LOG) asm volatile("v_log_f32 %0, %0" : "+v"(x[i]));
+            if constexpr (OP == BFI) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(x[i]) : "v"(c1), "v"(c2));
+            if constexpr (OP == MIX) {
+                // the mix of the check-node rule per pair of edges: 8 transcendentals, 12 packed, 2 bit operations
+                if (i < 8) {
+                    if ((i & 3) == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+                    else if ((i & 3) == 3) asm volatile("v_log_f32 %0, %0" : "+v"(x[i]));
+                    else asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]));
+                } else if (i < 14) {
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n\tv_pk_mul_f32 %0, %0, %1" : "+v"(y[i]) : "v"(p1), "v"(p2));
+                } else {
+                    asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(x[i]) : "v"(c1), "v"(c2));
+                }
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += x[i] + y[i].x + y[i].y;
+    if (s == 1234.5678f) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) cycles[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int OP>
+void run(const char* name, int insts_per_rep, unsigned long long* d_cycles, float* d_sink, int cus) {
+    printf("%-34s", name);
+    for (int k : {1, 2, 3, 4, 6, 8}) {
+        const int blocks = cus * k;
+        CK(hipMemset(d_cycles, 0, (size_t)blocks * 4 * sizeof(unsigned long long)));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(rate_k<OP>, dim3(blocks), dim3(256), 0, 0, d_cycles, d_sink, 1.0f);  // warm
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(rate_k<OP>, dim3(blocks), dim3(256), 0, 0, d_cycles, d_sink, 1.0f);
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> h((size_t)blocks * 4);
+        CK(hipMemcpy(h.data(), d_cycles, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::sort(h.begin(), h.end());
+        const double per_inst = (double)h[h.size() / 2] / ((double)REPS * insts_per_rep);
+        // clock the chip held: cycles of the median wave / wall time of the launch (one round of waves)
+        printf("  k=%d: %5.2f (%4.2f/SIMD, %4.2f GHz)", k, per_inst, per_inst / k, (double)h[h.size() / 2] / (ms * 1e6));
+        CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    }
+    printf("\n");
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("%s, %d CUs; cycles of wave lifetime per wave64 instruction at k waves per SIMD (per-SIMD cycles, clock held)\n",
+           prop.name, cus);
+    unsigned long long* d_cycles;
+    float* d_sink;
+    CK(hipMalloc(&d_cycles, (size_t)cus * 8 * 4 * sizeof(unsigned long long)));
+    CK(hipMalloc(&d_sink, 64));
+    run<FMA>("v_fma_f32", 16, d_cycles, d_sink, cus);
+    run<PK_FMA>("v_pk_fma_f32", 16, d_cycles, d_sink, cus);
+    run<PK_MUL>("v_pk_mul_f32", 16, d_cycles, d_sink, cus);
+    run<PK_ADD>("v_pk_add_f32", 16, d_cycles, d_sink, cus);
+    run<BFI>("v_bfi_b32", 16, d_cycles, d_sink, cus);
+    run<EXP>("v_exp_f32", 16, d_cycles, d_sink, cus);
+    run<RCP>("v_rcp_f32", 16, d_cycles, d_sink, cus);
+    run<LOG>("v_log_f32", 16, d_cycles, d_sink, cus);
+    run<MIX>("mix 8 trans + 12 packed + 2 bfi", 22, d_cycles, d_sink, cus);
+    return 0;
+}
