@@ -30,15 +30,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 SIMDS = 256 * 4            # compute units x SIMD-32 units
 CLOCK_HZ = 2.4e9           # maximum shader clock; under this load the chip holds less, so fractions of these
                            # ceilings are lower bounds
-# Vector-issue cycles one SIMD needs for 64 edge-iterations (one per lane), at the least:
-#   4 transcendentals per edge (2^|beta|, the reciprocal that gives q, 1/Q, log2), each an instruction of its
-#   own at 8 issue cycles;
-#   12 plain fp32 operations per edge, two edges to a packed instruction (v_pk_*) of 4 issue cycles.  Check
-#   node: scaling of 2^|beta| (1), fma to the denominator of q (1), prefix step 1 - Q and fma (2), suffix
-#   step likewise (2), fma joining prefix and suffix (1), fma(1/Q, 2, -1) (1), product of all signs, own
-#   sign out of it, sign onto the magnitude (3); variable node: prefix add, suffix add, their sum (3); that is
-#   14, of which the first prefix step and the last suffix step of a node are not needed: 12 on average.
-VALU_FLOOR_CYCLES_PER_64_EDGE_ITERS = 4 * 8 + (12 / 2) * 4
+# Vector-issue cycles one SIMD needs for 64 edge-iterations (one per lane), at the least, priced with the issue
+# rates measured on this chip with every SIMD saturated (tools/valu_rates.hip, profiles/r02/r02_valu_issue_rates.txt:
+# v_exp / v_rcp / v_log 8.1 SIMD cycles per wave64 instruction, a packed fp32 instruction 4.45 = 2.225 per
+# element, a plain fp32 instruction 2.3 - 2.5; the costs of a mix add up):
+#   4 transcendentals per edge (2^|beta|, the reciprocal that gives q, 1/Q, log2);
+#   12 fp32 operations per edge.  Check node: scaling of 2^|beta| (1), fma to the denominator of q (1), prefix
+#   step 1 - Q and fma (2), suffix step likewise (2), fma joining prefix and suffix (1), fma(1/Q, 2, -1) (1),
+#   product of all signs, own sign out of it, sign onto the magnitude (3); variable node: prefix add, suffix
+#   add, their sum (3); that is 14, of which the first prefix step and the last suffix step of a node are not
+#   needed: 12 on average.
+TRANS_CYCLES, FP32_ELEMENT_CYCLES = 8.1, 2.225
+VALU_FLOOR_CYCLES_PER_64_EDGE_ITERS = 4 * TRANS_CYCLES + 12 * FP32_ELEMENT_CYCLES
 # LDS cycles of one CU per edge-iteration at the data-path rates of the access shapes used: check side
 # ds_read_b128 (256 B/clk) and ds_write_b128 (79 B/clk), variable side ds_read_b32 (128 B/clk) and
 # ds_write_b32 (64 B/clk), 4 bytes each
@@ -338,9 +341,10 @@ def main(argv=None):
         roofline = {
             "bound": "valu_issue", "achieved": edge_iters / 1e12, "peak": valu_peak / 1e12, "unit": "Tedge-iterations/s",
             "frac": edge_iters / valu_peak,
-            "peak_definition": "1024 SIMDs x 2.4 GHz x 64 lanes / %.0f issue cycles per 64 edge-iterations "
-                               "(4 transcendentals x 8 cycles + 12 fp32 operations in 6 packed instructions x 4 cycles)"
-                               % VALU_FLOOR_CYCLES_PER_64_EDGE_ITERS,
+            "peak_definition": "1024 SIMDs x 2.4 GHz x 64 lanes / %.1f issue cycles per 64 edge-iterations "
+                               "(4 transcendentals x %.1f cycles + 12 fp32 operations x %.3f cycles, the issue rates "
+                               "measured by tools/valu_rates.hip)"
+                               % (VALU_FLOOR_CYCLES_PER_64_EDGE_ITERS, TRANS_CYCLES, FP32_ELEMENT_CYCLES),
             "lds_ceiling": {"peak": lds_peak / 1e12, "unit": "Tedge-iterations/s", "frac": edge_iters / lds_peak,
                             "peak_definition": "256 CUs x 2.4 GHz / %.3f LDS cycles per edge-iteration (b128 read and "
                                                "write on the check side, b32 read and write on the variable side)"

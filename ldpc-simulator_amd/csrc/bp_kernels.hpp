@@ -236,15 +236,17 @@ __device__ __forceinline__ void cn_complement(V (&b)[D]) {
         sg[k] = vsign1(b[k]);
         q[k] = tanh_complement<V>(b[k]);
         pq[k] = Q;
-        Q = vfma(q[k], one - Q, Q);
+        // the first step is fma(q, 1 - 0, 0) = q exactly (q is never -0; NaN stays NaN): no instruction
+        Q = (k == 0) ? q[k] : vfma(q[k], one - Q, Q);
         all = all * sg[k];
     }
     V sQ = vsplat<V>(0.0f);
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
-        const V mag = atanh2_complement<V>(vfma(sQ, one - pq[k], pq[k]));
+        // for the last member the suffix is empty: fma(0, 1 - pq, pq) = pq exactly (pq lies in [0, 1] or is NaN)
+        const V mag = atanh2_complement<V>((k == D - 1) ? pq[k] : vfma(sQ, one - pq[k], pq[k]));
         b[k] = mag * (all * sg[k]);
-        sQ = vfma(q[k], one - sQ, sQ);
+        sQ = (k == D - 1) ? q[k] : vfma(q[k], one - sQ, sQ);
     }
 }
 

@@ -15,12 +15,12 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int REPS = 2048;
+constexpr int REPS = 16384;
 
-enum Op { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, LOG, BFI, MIX };
+enum Op { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, LOG, BFI, MIX, XOR, AND_OR, MUL, ADD, FMAC, CNDMASK, LDEXP, ADD_ABS, FMA_K };
 
 template <int OP>
-__global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, float* sink, float seed) {
+__global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, unsigned long long* ticks, float* sink, float seed) {
     float x[16];
     v2f y[16];
 #pragma unroll
@@ -28,6 +28,7 @@ __global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, float*
     const float c1 = 0.999f, c2 = 0.0001f;
     const v2f p1 = v2f{0.999f, 0.998f}, p2 = v2f{0.0001f, 0.0002f};
     __syncthreads();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < REPS; ++r) {
 #pragma unroll
@@ -40,6 +41,15 @@ __global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, float*
             if constexpr (OP == RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]));
             if constexpr (OP == LOG) asm volatile("v_log_f32 %0, %0" : "+v"(x[i]));
             if constexpr (OP == BFI) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(x[i]) : "v"(c1), "v"(c2));
+            if constexpr (OP == XOR) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[i]) : "v"(c1));
+            if constexpr (OP == AND_OR) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(c1), "v"(c2));
+            if constexpr (OP == MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(c1));
+            if constexpr (OP == ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(c2));
+            if constexpr (OP == FMAC) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[i]) : "v"(c1), "v"(c2));
+            if constexpr (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(c1));
+            if constexpr (OP == LDEXP) asm volatile("v_ldexp_f32 %0, %0, 1" : "+v"(x[i]));
+            if constexpr (OP == ADD_ABS) asm volatile("v_add_f32_e64 %0, |%0|, %1" : "+v"(x[i]) : "v"(c2));
+            if constexpr (OP == FMA_K) asm volatile("v_fma_f32 %0, %0, 0.5, 0.5" : "+v"(x[i]));
             if constexpr (OP == MIX) {
                 // the mix of the check-node rule per pair of edges: 8 transcendentals, 12 packed, 2 bit operations
                 if (i < 8) {
@@ -55,34 +65,44 @@ __global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, float*
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += x[i] + y[i].x + y[i].y;
     if (s == 1234.5678f) sink[0] = s;
-    if ((threadIdx.x & 63) == 0) cycles[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) {
+        cycles[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+        ticks[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = r1 - r0;
+    }
 }
 
 template <int OP>
-void run(const char* name, int insts_per_rep, unsigned long long* d_cycles, float* d_sink, int cus) {
+void run(const char* name, int insts_per_rep, unsigned long long* d_cycles, unsigned long long* d_ticks, float* d_sink, int cus) {
     printf("%-34s", name);
-    for (int k : {1, 2, 3, 4, 6, 8}) {
+    for (int k : {1, 2, 4, 8}) {
         const int blocks = cus * k;
-        CK(hipMemset(d_cycles, 0, (size_t)blocks * 4 * sizeof(unsigned long long)));
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(rate_k<OP>, dim3(blocks), dim3(256), 0, 0, d_cycles, d_sink, 1.0f);  // warm
+        hipLaunchKernelGGL(rate_k<OP>, dim3(blocks), dim3(256), 0, 0, d_cycles, d_ticks, d_sink, 1.0f);  // warm
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(rate_k<OP>, dim3(blocks), dim3(256), 0, 0, d_cycles, d_sink, 1.0f);
+        hipLaunchKernelGGL(rate_k<OP>, dim3(blocks), dim3(256), 0, 0, d_cycles, d_ticks, d_sink, 1.0f);
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
         float ms = 0.f;
         CK(hipEventElapsedTime(&ms, e0, e1));
-        std::vector<unsigned long long> h((size_t)blocks * 4);
+        std::vector<unsigned long long> h((size_t)blocks * 4), t((size_t)blocks * 4);
         CK(hipMemcpy(h.data(), d_cycles, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(t.data(), d_ticks, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<double> clk(h.size());
+        for (size_t i = 0; i < h.size(); ++i) clk[i] = (double)h[i] / (double)t[i] * 0.1;  // GHz: s_memrealtime ticks at 100 MHz
         std::sort(h.begin(), h.end());
-        const double per_inst = (double)h[h.size() / 2] / ((double)REPS * insts_per_rep);
-        // clock the chip held: cycles of the median wave / wall time of the launch (one round of waves)
-        printf("  k=%d: %5.2f (%4.2f/SIMD, %4.2f GHz)", k, per_inst, per_inst / k, (double)h[h.size() / 2] / (ms * 1e6));
+        std::sort(clk.begin(), clk.end());
+        const double ghz = clk[clk.size() / 2];
+        const double insts = (double)REPS * insts_per_rep;                  // per wave
+        const double per_wave = (double)h[h.size() / 2] / insts;            // cycles of wave lifetime per instruction
+        // chip-wide: SIMD cycles that passed during the launch per instruction a SIMD retired
+        const double per_simd = (ms * 1e6 * ghz) / (insts * k);
+        printf("  k=%d: %5.2f/wave %4.2f/SIMD %4.2f GHz", k, per_wave, per_simd, ghz);
         CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
     }
     printf("\n");
@@ -92,20 +112,31 @@ int main() {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    printf("%s, %d CUs; cycles of wave lifetime per wave64 instruction at k waves per SIMD (per-SIMD cycles, clock held)\n",
+    printf("%s, %d CUs; k workgroups of 4 waves per CU: cycles of wave lifetime per wave64 instruction (median wave), SIMD cycles per\n"
+           "instruction over the whole launch (wall time x clock / instructions per SIMD), in-kernel clock (s_memtime / s_memrealtime)\n",
            prop.name, cus);
-    unsigned long long* d_cycles;
+    unsigned long long *d_cycles, *d_ticks;
     float* d_sink;
     CK(hipMalloc(&d_cycles, (size_t)cus * 8 * 4 * sizeof(unsigned long long)));
+    CK(hipMalloc(&d_ticks, (size_t)cus * 8 * 4 * sizeof(unsigned long long)));
     CK(hipMalloc(&d_sink, 64));
-    run<FMA>("v_fma_f32", 16, d_cycles, d_sink, cus);
-    run<PK_FMA>("v_pk_fma_f32", 16, d_cycles, d_sink, cus);
-    run<PK_MUL>("v_pk_mul_f32", 16, d_cycles, d_sink, cus);
-    run<PK_ADD>("v_pk_add_f32", 16, d_cycles, d_sink, cus);
-    run<BFI>("v_bfi_b32", 16, d_cycles, d_sink, cus);
-    run<EXP>("v_exp_f32", 16, d_cycles, d_sink, cus);
-    run<RCP>("v_rcp_f32", 16, d_cycles, d_sink, cus);
-    run<LOG>("v_log_f32", 16, d_cycles, d_sink, cus);
-    run<MIX>("mix 8 trans + 12 packed + 2 bfi", 22, d_cycles, d_sink, cus);
+    run<FMA>("v_fma_f32", 16, d_cycles, d_ticks, d_sink, cus);
+    run<PK_FMA>("v_pk_fma_f32", 16, d_cycles, d_ticks, d_sink, cus);
+    run<PK_MUL>("v_pk_mul_f32", 16, d_cycles, d_ticks, d_sink, cus);
+    run<PK_ADD>("v_pk_add_f32", 16, d_cycles, d_ticks, d_sink, cus);
+    run<BFI>("v_bfi_b32", 16, d_cycles, d_ticks, d_sink, cus);
+    run<EXP>("v_exp_f32", 16, d_cycles, d_ticks, d_sink, cus);
+    run<RCP>("v_rcp_f32", 16, d_cycles, d_ticks, d_sink, cus);
+    run<LOG>("v_log_f32", 16, d_cycles, d_ticks, d_sink, cus);
+    run<MIX>("mix 8 trans + 12 packed + 2 bfi", 22, d_cycles, d_ticks, d_sink, cus);
+    run<XOR>("v_xor_b32 (VOP2)", 16, d_cycles, d_ticks, d_sink, cus);
+    run<AND_OR>("v_and_or_b32", 16, d_cycles, d_ticks, d_sink, cus);
+    run<MUL>("v_mul_f32 (VOP2)", 16, d_cycles, d_ticks, d_sink, cus);
+    run<ADD>("v_add_f32 (VOP2)", 16, d_cycles, d_ticks, d_sink, cus);
+    run<FMAC>("v_fmac_f32 (VOP2)", 16, d_cycles, d_ticks, d_sink, cus);
+    run<CNDMASK>("v_cndmask_b32", 16, d_cycles, d_ticks, d_sink, cus);
+    run<LDEXP>("v_ldexp_f32", 16, d_cycles, d_ticks, d_sink, cus);
+    run<ADD_ABS>("v_add_f32 |x| (VOP3)", 16, d_cycles, d_ticks, d_sink, cus);
+    run<FMA_K>("v_fma_f32 inline constants", 16, d_cycles, d_ticks, d_sink, cus);
     return 0;
 }
