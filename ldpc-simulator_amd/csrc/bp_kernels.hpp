@@ -68,15 +68,29 @@ struct BpParams {
 };
 
 // ---- vector access helpers: FPL consecutive floats / words per lane -------------------
+// LDPC_MSG_NT (set by a translation unit before this header): rows of four frames per lane (1 KiB per wave
+// access, the fixed-iteration sweeps of codes with degrees <= 8) are read and written with non-temporal
+// accesses.  A sweep touches every message of a tile once and the next touch is a whole sweep later, far
+// beyond what the caches hold, so nothing is gained by keeping the lines: in-place read-modify-write streams
+// measured 5.6 TB/s with non-temporal accesses against 5.2 TB/s without (tools/membw.hip), the sweeps +2 % to
+// +3.5 %.  One-frame-per-lane rows stay on the default policy: with early termination the lanes of finished
+// frames sit out, and partial rows written past the caches measured 6 - 11 % slower.
+#ifndef LDPC_MSG_NT
+#define LDPC_MSG_NT 0
+#endif
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 template <int FPL>
 __device__ __forceinline__ void ldv(const float* p, float (&v)[FPL]) {
     if constexpr (FPL == 1) {
         v[0] = p[0];
     } else if constexpr (FPL == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(p);
+        const f2v t = *reinterpret_cast<const f2v*>(p);
         v[0] = t.x; v[1] = t.y;
     } else {
-        const float4 t = *reinterpret_cast<const float4*>(p);
+        const f4v t = LDPC_MSG_NT ? __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p)) : *reinterpret_cast<const f4v*>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
 }
@@ -85,9 +99,10 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[FPL]) {
     if constexpr (FPL == 1) {
         p[0] = v[0];
     } else if constexpr (FPL == 2) {
-        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+        *reinterpret_cast<f2v*>(p) = f2v{v[0], v[1]};
     } else {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        const f4v t = {v[0], v[1], v[2], v[3]};
+        if (LDPC_MSG_NT) __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(p)); else *reinterpret_cast<f4v*>(p) = t;
     }
 }
 template <int FPL>

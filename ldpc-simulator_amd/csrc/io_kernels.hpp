@@ -144,47 +144,69 @@ __global__ void __launch_bounds__(256) gen_awgn_kernel(int n, float a, float b, 
 }
 
 // ---- source: random codewords u * G (GenerateC.java:12-24) --------------------------------------------
-// Gp[k][nw]: rows of the generator matrix packed 32 columns per word.  Message bit i of a frame is bit
-// (i & 127) of the Philox block (frame, i >> 7, stream 2).  A block encodes 8 frames at once so that
-// every word of G it reads serves 8 frames.
-__global__ void __launch_bounds__(256) gen_codewords_kernel(int n, int nw, int k, const uint32_t* Gp, uint64_t seed,
+// Message bit i of a frame is bit (i & 127) of the Philox block (frame, i >> 7, stream 2).
+// A block encodes 64 frames at once, bit-sliced over the frames: U[i] holds message bit i of the 64 frames
+// in one 64-bit word, and the 64 code bits at position j are the XOR of U[i] over the ones of column j of
+// G.  GT[n][kw64] is G by columns, 64 rows to a word, so a position walks the set bits of its own column:
+// a column of the identity part of a systematic G costs one step, a parity column about k / 2, and every
+// step serves 64 frames (a frame-by-frame product reads all of G for every few frames).
+constexpr int kCwFrames = 64;   // frames per block
+
+__global__ void __launch_bounds__(256) gen_codewords_kernel(int n, int k, const unsigned long long* GT, uint64_t seed,
                                                             long long first_frame, long long frames, uint8_t* cw) {
-    extern __shared__ uint32_t ubits[];  // [8][kw] message bits of the block's frames
-    const int kw = (k + 31) >> 5;
-    const long long f0 = (long long)blockIdx.x * 8;
-    for (int idx = threadIdx.x; idx < 8 * ((k + 127) >> 7); idx += blockDim.x) {
-        const int fr = idx / ((k + 127) >> 7), g = idx % ((k + 127) >> 7);
+    extern __shared__ unsigned long long cw_lds[];
+    const int kw32 = (k + 31) >> 5, kw64 = (k + 63) >> 6, groups = (k + 127) >> 7;
+    const int raw_stride = kw32 | 1;                       // odd: the 64 lanes of a transposing read hit 64 banks
+    unsigned long long* U = cw_lds;                        // [kw64 * 64] message bit i of the 64 frames
+    unsigned long long* stage = U + (size_t)kw64 * 64;     // [256] code bits of the positions in flight
+    uint32_t* raw = reinterpret_cast<uint32_t*>(stage + 256);   // [64][raw_stride] message words by frame
+    const long long f0 = (long long)blockIdx.x * kCwFrames;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int idx = threadIdx.x; idx < kCwFrames * groups; idx += blockDim.x) {
+        const int fr = idx / groups, g = idx - fr * groups;
         const u32x4 x = frame_block(seed, (uint64_t)(first_frame + f0 + fr), (uint32_t)g, 2u);
         const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
         for (int q = 0; q < 4; ++q)
-            if (4 * g + q < kw) ubits[fr * kw + 4 * g + q] = xs[q];
+            if (4 * g + q < kw32) raw[fr * raw_stride + 4 * g + q] = xs[q];
     }
     __syncthreads();
-    for (int w = threadIdx.x; w < nw; w += blockDim.x) {
-        uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < k; ++i) {
-            const uint32_t g = Gp[(long long)i * nw + w];
-#pragma unroll
-            for (int fr = 0; fr < 8; ++fr)
-                acc[fr] ^= ((ubits[fr * kw + (i >> 5)] >> (i & 31)) & 1u) ? g : 0u;
-        }
-        for (int fr = 0; fr < 8; ++fr) {
-            const long long f = f0 + fr;
-            if (f >= frames) break;
-            uint8_t* o = cw + f * n + 32 * w;
-            if ((n & 31) == 0) {  // 32 bytes, 16-byte aligned: bit b of the word -> byte b
-                uint32_t q[8];
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const uint32_t nib = (acc[fr] >> (4 * b)) & 15u;
-                    q[b] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+    for (int i = wave; i < kw64 * 64; i += 4) {            // lane = frame: one ballot transposes bit i
+        const bool bit = i < k && ((raw[lane * raw_stride + (i >> 5)] >> (i & 31)) & 1u);
+        const unsigned long long mask = __ballot(bit);
+        if (lane == 0) U[i] = mask;
+    }
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        unsigned long long acc = 0ull;
+        if (j < n) {
+            const unsigned long long* col = GT + (size_t)j * kw64;
+            for (int w = 0; w < kw64; ++w) {
+                unsigned long long bits = col[w];
+                while (bits) {
+                    acc ^= U[w * 64 + __builtin_ctzll(bits)];
+                    bits &= bits - 1;
                 }
-                reinterpret_cast<uint4*>(o)[0] = make_uint4(q[0], q[1], q[2], q[3]);
-                reinterpret_cast<uint4*>(o)[1] = make_uint4(q[4], q[5], q[6], q[7]);
-            } else {
-                for (int b = 0; b < 32 && 32 * w + b < n; ++b) o[b] = (uint8_t)((acc[fr] >> b) & 1u);
             }
         }
+        stage[threadIdx.x] = acc;
+        __syncthreads();
+        // bit fr of stage[p] -> byte cw[f0 + fr][j0 + p]: a wave writes 256 consecutive bytes of one frame
+        for (int fr = wave; fr < kCwFrames; fr += 4) {
+            const long long f = f0 + fr;
+            if (f >= frames) break;
+            const int p = 4 * lane;
+            uint8_t* o = cw + f * n + j0 + p;
+            uint32_t b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] = (uint32_t)((stage[p + q] >> fr) & 1ull);
+            if (j0 + p + 3 < n && ((n | j0) & 3) == 0) {
+                *reinterpret_cast<uint32_t*>(o) = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+            } else {
+                for (int q = 0; q < 4 && j0 + p + q < n; ++q) o[q] = (uint8_t)b[q];
+            }
+        }
+        __syncthreads();
     }
 }
 

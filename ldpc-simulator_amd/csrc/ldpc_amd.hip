@@ -61,9 +61,10 @@ struct ldpc_amd_ctx {
     hipEvent_t io_decoded[2] = {nullptr, nullptr};
     unsigned long long* d_counters = nullptr;
     size_t counters_len = 0;
-    // generator matrix for random codewords: k rows packed 32 columns per word (null = all-zero word)
+    // generator matrix for random codewords, by columns: n columns of ceil(k / 64) words, row i at bit i & 63
+    // of word i >> 6 (null = all-zero word)
     int gen_k = 0;
-    uint32_t* d_gen = nullptr;
+    unsigned long long* d_gen = nullptr;
     void* stage_cw = nullptr;
     size_t stage_cw_bytes = 0;
     // tables of the frame-resident engine (built on first use, see build_resident_tables)
@@ -802,9 +803,14 @@ int gen_codewords(ldpc_amd_ctx* c, uint64_t seed, long long first_frame, long lo
         LDPC_HIP(c, hipMemsetAsync(d_cw, 0, (size_t)frames * c->n, s));
         return LDPC_AMD_OK;
     }
-    const int kw = (c->gen_k + 31) / 32;
-    hipLaunchKernelGGL(gen_codewords_kernel, dim3((unsigned)((frames + 7) / 8)), dim3(256), (size_t)8 * kw * 4, s, c->n,
-                       c->nw, c->gen_k, c->d_gen, seed, first_frame, frames, d_cw);
+    const size_t kw32 = (size_t)(c->gen_k + 31) / 32, kw64 = (size_t)(c->gen_k + 63) / 64;
+    // U | stage | raw (see gen_codewords_kernel)
+    const size_t lds = (kw64 * 64 + 256) * sizeof(unsigned long long) + (size_t)kCwFrames * (kw32 | 1) * sizeof(uint32_t);
+    if (lds > 160 * 1024) return fail(c, LDPC_AMD_ELIMIT, "gen_codewords: generator matrices of more than about 13,000 rows are not supported");
+    auto kern = gen_codewords_kernel;
+    LDPC_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((frames + kCwFrames - 1) / kCwFrames)), dim3(256), lds, s, c->n, c->gen_k,
+                       c->d_gen, seed, first_frame, frames, d_cw);
     LDPC_HIP(c, hipGetLastError());
     return LDPC_AMD_OK;
 }
@@ -1151,12 +1157,13 @@ int ldpc_amd_set_generator(ldpc_amd_ctx* c, int32_t k, const uint8_t* G) {
     }
     if (k == 0 || !G) return LDPC_AMD_OK;
     if (k < 0) return fail(c, LDPC_AMD_EINVAL, "set_generator: k must be >= 0");
-    std::vector<uint32_t> packed((size_t)k * c->nw, 0u);
+    const size_t kw64 = ((size_t)k + 63) / 64;
+    std::vector<unsigned long long> packed((size_t)c->n * kw64, 0ull);
     for (int i = 0; i < k; ++i)
         for (int j = 0; j < c->n; ++j)
-            if (G[(size_t)i * c->n + j] & 1) packed[(size_t)i * c->nw + (j >> 5)] |= 1u << (j & 31);
-    LDPC_HIP(c, hipMalloc((void**)&c->d_gen, packed.size() * sizeof(uint32_t)));
-    LDPC_HIP(c, hipMemcpy(c->d_gen, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            if (G[(size_t)i * c->n + j] & 1) packed[(size_t)j * kw64 + (i >> 6)] |= 1ull << (i & 63);
+    LDPC_HIP(c, hipMalloc((void**)&c->d_gen, packed.size() * sizeof(unsigned long long)));
+    LDPC_HIP(c, hipMemcpy(c->d_gen, packed.data(), packed.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     c->gen_k = k;
     return LDPC_AMD_OK;
 }

@@ -21,7 +21,7 @@ def test_codewords_bit_exact(sys_code, oracle):
     c = sys_code
     dec, n = c["dec"], c["n"]
     dec.set_generator(c["eg"])
-    for first, F in ((0, 8), (123456789012, 301), (7, 1)):      # ragged: not a multiple of the 8 frames a block encodes
+    for first, F in ((0, 8), (123456789012, 301), (7, 1), (5, 64), (5, 65)):   # ragged: a block encodes 64 frames
         d_cw = torch.full((F, n), 9, dtype=torch.uint8, device="cuda")
         dec.gen_codewords_dev(42, first, F, d_cw.data_ptr())
         torch.cuda.synchronize()
@@ -37,18 +37,19 @@ def test_codewords_bit_exact(sys_code, oracle):
 
 
 def test_codewords_odd_length(pkg, oracle):
-    """n not a multiple of 32 and k not a multiple of 32 or 128: the byte-wise tail paths."""
+    """n not a multiple of 4, 32 or 256 and k not a multiple of 32, 64 or 128: the tail paths; dense G."""
     import torch
     rng = np.random.default_rng(5)
-    m, n, k = 30, 75, 45
-    G = rng.integers(0, 2, (k, n)).astype(np.uint8)
-    rows, cols = np.nonzero(rng.random((m, n)) < 0.1)
-    dec = pkg.Decoder(m, n, rows, cols)
-    dec.set_generator(G)
-    d_cw = torch.empty((19, n), dtype=torch.uint8, device="cuda")
-    dec.gen_codewords_dev(3, 100, 19, d_cw.data_ptr())
-    torch.cuda.synchronize()
-    assert (d_cw.cpu().numpy() == oracle.gen_codewords(G, 3, 100, 19)).all()
+    for m, n, k, F in ((30, 75, 45, 19), (100, 301, 130, 70), (200, 777, 577, 130)):
+        G = rng.integers(0, 2, (k, n)).astype(np.uint8)
+        rows, cols = np.nonzero(rng.random((m, n)) < 0.1)
+        dec = pkg.Decoder(m, n, rows, cols)
+        dec.set_generator(G)
+        d_cw = torch.empty((F, n), dtype=torch.uint8, device="cuda")
+        dec.gen_codewords_dev(3, 100, F, d_cw.data_ptr())
+        torch.cuda.synchronize()
+        assert (d_cw.cpu().numpy() == oracle.gen_codewords(G, 3, 100, F)).all(), (m, n, k)
+        dec.close()
 
 
 def test_channel_and_counts_with_codewords(sys_code, oracle):

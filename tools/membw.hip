@@ -22,6 +22,29 @@ __global__ void read_k(const float4* __restrict__ a, float* out, size_t n) {
 __global__ void write_k(float4* a, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
+// One block moves one contiguous chunk of U x 256 float4: U loads per lane are in flight before the first store,
+// the grid covers the buffer exactly (no grid-stride loop).  NTL / NTS: non-temporal loads / stores.
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int U, bool NTL, bool NTS, bool INPLACE>
+__global__ void __launch_bounds__(256) chunk_k(const float4* __restrict__ a4, float4* __restrict__ b4) {
+    const f4* a = reinterpret_cast<const f4*>(a4);
+    f4* b = reinterpret_cast<f4*>(b4);
+    const size_t base = (size_t)blockIdx.x * (U * 256) + threadIdx.x;
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (NTL) v[u] = __builtin_nontemporal_load(&a[base + (size_t)u * 256]);
+        else v[u] = a[base + (size_t)u * 256];
+    }
+    f4* out = INPLACE ? const_cast<f4*>(a) : b;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (INPLACE) { v[u].x += 1.f; v[u].y *= 1.0001f; }
+        if (NTS) __builtin_nontemporal_store(v[u], &out[base + (size_t)u * 256]);
+        else out[base + (size_t)u * 256] = v[u];
+    }
+}
+
 // each wave owns a private contiguous region of `region` float4 and sweeps it `passes` times,
 // ROWS rows of 64 float4 (1 KiB) per step: load ROWS, modify, store ROWS (the CN sweep pattern)
 template <int ROWS, bool PREFETCH>
@@ -82,6 +105,17 @@ int main(int argc, char** argv) {
         printf("read   grid %5d: %7.1f GB/s\n", blocks, 1.0 * bytes / t / 1e6);
         t = time_ms([&] { hipLaunchKernelGGL(write_k, dim3(blocks), dim3(256), 0, 0, a, n4); });
         printf("write  grid %5d: %7.1f GB/s\n", blocks, 1.0 * bytes / t / 1e6);
+    }
+    {
+        float t;
+#define CHUNK(U, NTL, NTS, INP, label)                                                                              \
+        t = time_ms([&] { hipLaunchKernelGGL((chunk_k<U, NTL, NTS, INP>), dim3((unsigned)(n4 / (U * 256))), dim3(256), 0, 0, a, b); }); \
+        printf("%-6s chunk of %2d x 256 float4 per block, nt loads %d, nt stores %d: %7.1f GB/s (read+write)\n", label, U, NTL, NTS, 2.0 * bytes / t / 1e6);
+        CHUNK(4, false, false, false, "copy") CHUNK(8, false, false, false, "copy") CHUNK(16, false, false, false, "copy")
+        CHUNK(8, false, true, false, "copy") CHUNK(8, true, true, false, "copy") CHUNK(16, true, true, false, "copy")
+        CHUNK(4, true, true, false, "copy")
+        CHUNK(8, false, false, true, "rmw") CHUNK(8, false, true, true, "rmw") CHUNK(8, true, true, true, "rmw") CHUNK(16, true, true, true, "rmw")
+#undef CHUNK
     }
     // per-wave private regions: waves = blocks*4; region = bytes / waves
     for (int blocks : {512, 1024, 2048}) {
