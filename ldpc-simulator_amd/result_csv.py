@@ -80,7 +80,11 @@ def leg_statistics(counters, m, n):
     info_bits, mis = c[capi.CNT_INFO_BIT_ERRORS], c[capi.CNT_MISCORRECTED]
     # per-frame channel error rate x_f = errors_f / k: mean = sum x_f / F, variance = sum (x_f - mean)^2 / F
     mean = _jdiv(_jdiv(c[capi.CNT_CHANNEL_ERRORS], k), frames)
-    var = _jdiv(_jdiv(c[capi.CNT_CHANNEL_ERRORS_SQ], k * k), frames) - mean * mean if frames and k else float("nan")
+    # The reference sums (x_f - mean)^2 over the frames (:221-228); from the two integer sums that is
+    # (F * sum e_f^2 - (sum e_f)^2) / (k^2 F^2), formed in exact integer arithmetic and rounded once, instead of
+    # the cancelling difference E[x^2] - mean^2 of two rounded doubles.
+    S, SQ = c[capi.CNT_CHANNEL_ERRORS], c[capi.CNT_CHANNEL_ERRORS_SQ]
+    var = (frames * SQ - S * S) / (k * k * frames * frames) if frames and k else float("nan")
     return {
         "channel_ber_mean": mean,
         "channel_ber_var": max(var, 0.0) if var == var else var,
