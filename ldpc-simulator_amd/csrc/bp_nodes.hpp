@@ -41,6 +41,7 @@ struct NodesParams {
     float* msg;          // [frames][E]
     float* lam;          // [frames][n]
     int32_t* synd_acc;   // [frames][max_iters], zero on entry
+    unsigned* bar;       // [2] grid barrier: arrivals counter, time-out flag; zero on entry
     uint8_t* hard;       // [frames][n]
     int32_t* out_iters;
     int32_t* out_synd;
@@ -61,8 +62,39 @@ __device__ __forceinline__ void nodes_syndrome(const NodesParams& p, int f, int 
     if (lane == 0 && cnt) atomicAdd(acc, cnt);
 }
 
+// Grid-wide barrier on one monotonic counter: every workgroup adds 1 and waits until the counter has reached
+// the number of workgroups times the number of barriers so far.  Visibility of the phase's plain stores to the
+// other compute units and XCDs: every wave drains its stores, the workgroup meets, one lane releases at agent
+// scope (write-back of the XCD's L2), drains again and only then arrives; after the poll has matched the same
+// lane acquires at agent scope (invalidate of this CU's L1) and the workgroup meets again before anyone
+// loads.  The grid is launched cooperatively, so all workgroups are resident and the wait ends; it is bounded
+// all the same (about 0.2 s): a time-out raises bar[1], every later barrier falls through at once, the kernel
+// finishes with meaningless results and the host reports the flag as an error.
+__device__ __forceinline__ void nodes_grid_barrier(unsigned* bar, unsigned& target, unsigned blocks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        target += blocks;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 21) || __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
 template <int RULE>
 __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
+    unsigned bar_target = 0u;   // arrivals the counter shows once everyone has passed the next barrier (lane 0 of a block)
     const long long gsize = (long long)gridDim.x * blockDim.x;
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -85,7 +117,7 @@ __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
         p.lam[at] = v;
         p.hard[at] = 0;
     }
-    cooperative_groups::this_grid().sync();
+    nodes_grid_barrier(p.bar, bar_target, gridDim.x);
 
     const uint32_t all = p.frames >= 32 ? 0xffffffffu : ((1u << p.frames) - 1u);
     uint32_t done = 0u;  // bit f: frame f has converged; the same in every thread of the grid
@@ -104,7 +136,7 @@ __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
                 else         cn_dispatch<1, RULE, false>(d, row, lam, p.edge_col + e0, 1, 1, nullptr, 0, lane);
             }
         }
-        cooperative_groups::this_grid().sync();
+        nodes_grid_barrier(p.bar, bar_target, gridDim.x);
         if (p.early && it > 0) {
             for (int f = 0; f < p.frames; ++f) {
                 if (((done >> f) & 1u) == 0u && p.synd_acc[(long long)f * L + (it - 1)] == 0) {  // "sumSyndro == 0", :117
@@ -129,7 +161,7 @@ __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
                            nullptr, 0, lane);
             p.hard[(long long)f * p.n + j] = (g[0] < 0.0f) ? 1 : 0;  // "(gamma[j] < 0) ? 1 : 0", :104
         }
-        cooperative_groups::this_grid().sync();
+        nodes_grid_barrier(p.bar, bar_target, gridDim.x);
     }
     if (done != all) {  // frames that ran all iterations: weight of the last syndrome (:115, :122)
         for (long long item = gtid; item < cn_items; item += gsize) {
@@ -137,7 +169,7 @@ __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
             if ((done >> f) & 1u) continue;
             nodes_syndrome(p, f, i, p.synd_acc + (long long)f * L + (L - 1), lane);
         }
-        cooperative_groups::this_grid().sync();
+        nodes_grid_barrier(p.bar, bar_target, gridDim.x);
         if (gtid == 0) {
             for (int f = 0; f < p.frames; ++f) {
                 if ((done >> f) & 1u) continue;

@@ -78,6 +78,7 @@ struct ldpc_amd_ctx {
     long long nodes_refusals = 0;   // cooperative launches the runtime refused
     int nodes_refused_in_a_row = 0;
     int nodes_last_error = 0;       // hipError_t of the last refusal
+    unsigned* nodes_bar = nullptr;  // barrier words of the last node-parallel launch (bar[1]: time-out flag)
     int* d_genres = nullptr;
     // timing of the last decode
     std::vector<hipEvent_t> ev;
@@ -533,7 +534,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         }
         if (use) {
             const size_t F = (size_t)frames;
-            const size_t need = F * ((size_t)c->E + (size_t)n + (size_t)max_iters) * sizeof(float);
+            const size_t need = (F * ((size_t)c->E + (size_t)n + (size_t)max_iters) + 2) * sizeof(float);
             if (c->ws_bytes < need) {
                 if (c->ws) {
                     LDPC_HIP(c, hipFree(c->ws));
@@ -554,8 +555,10 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             q.msg = (float*)c->ws;
             q.lam = q.msg + F * (size_t)c->E;
             q.synd_acc = (int32_t*)(q.lam + F * (size_t)n);
+            q.bar = (unsigned*)(q.synd_acc + F * (size_t)max_iters);
+            c->nodes_bar = q.bar;
             q.hard = d_hard; q.out_iters = d_iters; q.out_synd = d_synd;
-            LDPC_HIP(c, hipMemsetAsync(q.synd_acc, 0, F * (size_t)max_iters * sizeof(int32_t), s));
+            LDPC_HIP(c, hipMemsetAsync(q.synd_acc, 0, (F * (size_t)max_iters + 2) * sizeof(int32_t), s));
             NodesLaunch l;
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
                      : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
@@ -753,6 +756,15 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             LDPC_HIP(c, hipGetLastError());
         }
     }
+    return LDPC_AMD_OK;
+}
+
+// After the stream has been synchronised: did a grid barrier of the last node-parallel launch time out?
+int check_nodes_barrier(ldpc_amd_ctx* c) {
+    if (!c->nodes_bar || !c->timed_launches || strcmp(c->last_kernel, "bp_nodes_kernel")) return LDPC_AMD_OK;
+    unsigned flag = 0;
+    LDPC_HIP(c, hipMemcpy(&flag, c->nodes_bar + 1, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag) return fail(c, LDPC_AMD_EHIP, "bp_nodes_kernel: a grid barrier timed out; the results of that decode are invalid");
     return LDPC_AMD_OK;
 }
 
@@ -1133,7 +1145,7 @@ static int decode_host(ldpc_amd_ctx* c, const void* in, size_t in_elem, bool bsc
     if (int rc = copy_out(chunks - 1)) return rc;
     LDPC_HIP(c, hipStreamSynchronize(c->io_stream[0]));
     LDPC_HIP(c, hipStreamSynchronize(c->io_stream[1]));
-    return LDPC_AMD_OK;
+    return check_nodes_barrier(c);
 }
 
 int ldpc_amd_decode_batch(ldpc_amd_ctx* c, const float* llr, int64_t frames, int32_t max_iters, int32_t early_term,
@@ -1335,6 +1347,7 @@ int ldpc_amd_last_decode_timing(ldpc_amd_ctx* c, int32_t* launches, double* kern
         LDPC_HIP(c, hipEventElapsedTime(&ms, c->ev[(size_t)(2 * i)], c->ev[(size_t)(2 * i + 1)]));
         total += ms;
     }
+    if (int rc = check_nodes_barrier(c)) return rc;
     if (launches) *launches = c->timed_launches;
     if (kernel_ms) *kernel_ms = total;
     if (frames) *frames = c->timed_frames;

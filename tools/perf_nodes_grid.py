@@ -28,10 +28,10 @@ def run(name, code, F, iters, early, ebn0, grids):
     dec.close()
 
 
-G = (16, 32, 64, 128, 256)
+G = (32, 64, 128, 256, 512, 1024)
 c5 = L.codes.regular_ldpc(64800, 3, 6, 1)
 bg = L.codes.nr_bg1_shaped(384, 1)[1]
-for F in (1, 2, 4, 8):
+for F in (1, 4, 16, 32):
     run("C5 (3,6) n=64800", c5, F, 50, False, 1.6, G)
-for F in (1, 4):
+for F in (1, 8, 32):
     run("C4 BG1-shaped Z=384", bg, F, 50, False, 2.0, G)
