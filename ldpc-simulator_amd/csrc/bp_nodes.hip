@@ -4,7 +4,6 @@
 // to the streaming engine (kNodesMaxDc / kNodesMaxDv)
 #define LDPC_REG_DEG_CN 20
 #define LDPC_REG_DEG_VN 32
-#include <hip/hip_cooperative_groups.h>
 
 #include <algorithm>
 

@@ -25,6 +25,7 @@ namespace ldpc {
 
 constexpr int kNodesMaxFrames = 32;                   // one bit per frame in a register
 constexpr int kNodesMaxDc = 20, kNodesMaxDv = 32;     // degrees the register code of bp_nodes.hip covers
+constexpr int kNodesBarWords = 18;                    // words of grid-barrier state (NodesParams::bar)
 
 struct NodesParams {
     int m, n;
@@ -41,7 +42,7 @@ struct NodesParams {
     float* msg;          // [frames][E]
     float* lam;          // [frames][n]
     int32_t* synd_acc;   // [frames][max_iters], zero on entry
-    unsigned* bar;       // [2] grid barrier: arrivals counter, time-out flag; zero on entry
+    unsigned* bar;       // [kNodesBarWords] grid barrier state (nodes_grid_barrier); zero on entry
     uint8_t* hard;       // [frames][n]
     int32_t* out_iters;
     int32_t* out_synd;
@@ -62,15 +63,31 @@ __device__ __forceinline__ void nodes_syndrome(const NodesParams& p, int f, int 
     if (lane == 0 && cnt) atomicAdd(acc, cnt);
 }
 
-// Grid-wide barrier on one monotonic counter: every workgroup adds 1 and waits until the counter has reached
-// the number of workgroups times the number of barriers so far.  Visibility of the phase's plain stores to the
-// other compute units and XCDs: every wave drains its stores, the workgroup meets, one lane releases at agent
-// scope (write-back of the XCD's L2), drains again and only then arrives; after the poll has matched the same
-// lane acquires at agent scope (invalidate of this CU's L1) and the workgroup meets again before anyone
-// loads.  The grid is launched cooperatively, so all workgroups are resident and the wait ends; it is bounded
-// all the same (about 0.2 s): a time-out raises bar[1], every later barrier falls through at once, the kernel
-// finishes with meaningless results and the host reports the flag as an error.
-__device__ __forceinline__ void nodes_grid_barrier(unsigned* bar, unsigned& target, unsigned blocks) {
+// Grid-wide barrier.  The phase's plain stores sit in the L2 of the XCD that wrote them; an agent-scope release
+// writes that whole L2 back, and when every workgroup issues one (the simple barrier, `nodes_grid_barrier_flat`)
+// those write-backs are what the barrier costs (measured on one frame of n = 64800, 64 workgroups: 9 of 23 us
+// per iteration).  The barrier used between the phases therefore has two levels: every wave drains its stores
+// (s_waitcnt vmcnt(0): they have reached the L2), the workgroup meets, one lane adds 1 to the counter of its
+// XCD; the workgroup that completes its XCD's count issues the release for all of them - one write-back per XCD
+// and barrier - and only then adds 1 to the grid counter, on which every workgroup polls.  After the poll has
+// matched the lane acquires at agent scope (this CU's L1 and the L2 lines of other XCDs' data are dropped) and
+// the workgroup meets again before anyone loads.
+// bar[0] grid counter, bar[1] time-out flag, bar[2..9] arrivals per XCD, bar[10..17] workgroups per XCD; all
+// zero on entry, all monotonic.  The grid is launched cooperatively, so all workgroups are resident and the
+// waits end; they are bounded all the same (about 0.2 s): a time-out raises bar[1], every later barrier falls
+// through at once, the kernel finishes with meaningless results and the host reports the flag as an error.
+__device__ __forceinline__ void nodes_poll(unsigned* bar, unsigned target) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 21) || __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+
+__device__ __forceinline__ void nodes_grid_barrier_flat(unsigned* bar, unsigned& target, unsigned blocks) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -78,14 +95,33 @@ __device__ __forceinline__ void nodes_grid_barrier(unsigned* bar, unsigned& targ
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 21) || __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
+        nodes_poll(bar, target);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+struct NodesBarrier {
+    unsigned* bar;
+    unsigned grid_target;   // value of bar[0] once everyone has passed the next barrier
+    unsigned xcd_target;    // value of bar[2 + xcd] once every workgroup of this XCD has arrived
+    unsigned xcd, xcd_blocks, xcds;
+};
+
+__device__ __forceinline__ void nodes_grid_barrier(NodesBarrier& b) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        b.grid_target += b.xcds;
+        b.xcd_target += b.xcd_blocks;
+        const unsigned before = __hip_atomic_fetch_add(&b.bar[2 + b.xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before + 1u == b.xcd_target) {  // the last workgroup of this XCD: everyone's stores are in its L2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&b.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        nodes_poll(b.bar, b.grid_target);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -94,7 +130,16 @@ __device__ __forceinline__ void nodes_grid_barrier(unsigned* bar, unsigned& targ
 
 template <int RULE>
 __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
-    unsigned bar_target = 0u;   // arrivals the counter shows once everyone has passed the next barrier (lane 0 of a block)
+    // which XCD this workgroup runs on (XCC_ID, bits 3:0 of the hardware register); the workgroups count
+    // themselves per XCD before the first barrier, which is the flat one
+    NodesBarrier nb;
+    nb.bar = p.bar;
+    {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(id));
+        nb.xcd = id & 7u;
+    }
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&p.bar[10 + nb.xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const long long gsize = (long long)gridDim.x * blockDim.x;
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -117,7 +162,15 @@ __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
         p.lam[at] = v;
         p.hard[at] = 0;
     }
-    nodes_grid_barrier(p.bar, bar_target, gridDim.x);
+    nb.grid_target = 0u;
+    nodes_grid_barrier_flat(p.bar, nb.grid_target, gridDim.x);
+    nb.xcd_target = 0u;
+    nb.xcds = 0u;
+    for (unsigned x = 0; x < 8u; ++x) {
+        const unsigned cnt = __hip_atomic_load(&p.bar[10 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nb.xcds += cnt != 0u;
+        if (x == nb.xcd) nb.xcd_blocks = cnt;
+    }
 
     const uint32_t all = p.frames >= 32 ? 0xffffffffu : ((1u << p.frames) - 1u);
     uint32_t done = 0u;  // bit f: frame f has converged; the same in every thread of the grid
@@ -136,7 +189,7 @@ __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
                 else         cn_dispatch<1, RULE, false>(d, row, lam, p.edge_col + e0, 1, 1, nullptr, 0, lane);
             }
         }
-        nodes_grid_barrier(p.bar, bar_target, gridDim.x);
+        nodes_grid_barrier(nb);
         if (p.early && it > 0) {
             for (int f = 0; f < p.frames; ++f) {
                 if (((done >> f) & 1u) == 0u && p.synd_acc[(long long)f * L + (it - 1)] == 0) {  // "sumSyndro == 0", :117
@@ -161,7 +214,7 @@ __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
                            nullptr, 0, lane);
             p.hard[(long long)f * p.n + j] = (g[0] < 0.0f) ? 1 : 0;  // "(gamma[j] < 0) ? 1 : 0", :104
         }
-        nodes_grid_barrier(p.bar, bar_target, gridDim.x);
+        nodes_grid_barrier(nb);
     }
     if (done != all) {  // frames that ran all iterations: weight of the last syndrome (:115, :122)
         for (long long item = gtid; item < cn_items; item += gsize) {
@@ -169,7 +222,7 @@ __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
             if ((done >> f) & 1u) continue;
             nodes_syndrome(p, f, i, p.synd_acc + (long long)f * L + (L - 1), lane);
         }
-        nodes_grid_barrier(p.bar, bar_target, gridDim.x);
+        nodes_grid_barrier(nb);
         if (gtid == 0) {
             for (int f = 0; f < p.frames; ++f) {
                 if ((done >> f) & 1u) continue;

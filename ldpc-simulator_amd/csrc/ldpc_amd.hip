@@ -519,11 +519,12 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         const bool can = frames <= kNodesMaxFrames && c->m > 0 && c->max_dc <= kNodesMaxDc && c->max_dv <= kNodesMaxDv &&
                          c->nodes_blocks >= 0 && c->opt.engine != LDPC_AMD_ENGINE_STREAM;
         bool use = can;
-        // Per iteration this engine costs two grid barriers (about 20 us) plus about 64 ns per 1000 edges of
-        // the batch (gathers of single words); the sweep launches cost about 100 us of launches plus the
-        // longest wave's chain of dependent nodes, 32 variables of the largest degree (measured on an
-        // NR-BG1-sized code and on a (3,6) code of n = 64800: break-even at 32 and at 7 frames).
-        use = use && 20.0 + 6.4e-5 * (double)frames * (double)c->E < 100.0 + 5.8 * c->max_dv;
+        // Per iteration this engine costs two grid barriers and the latency of two dependent phases (about
+        // 14 us together) plus about 45 ns per 1000 edges of the batch (gathers of single words); the sweep
+        // launches cost about 100 us of launches plus the longest wave's chain of dependent nodes, 32
+        // variables of the largest degree (measured on an NR-BG1-sized code and on a (3,6) code of n = 64800:
+        // break-even beyond 32 frames and near 10 frames).
+        use = use && 14.0 + 4.5e-5 * (double)frames * (double)c->E < 100.0 + 5.8 * c->max_dv;
         if (c->opt.nodes >= 0) use = can && c->opt.nodes != 0;  // 0: never, 1: whenever the batch and the degrees allow
         if (use && c->nodes_blocks == 0) {
             int coop = 0, blocks = 0;
@@ -534,7 +535,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         }
         if (use) {
             const size_t F = (size_t)frames;
-            const size_t need = (F * ((size_t)c->E + (size_t)n + (size_t)max_iters) + 2) * sizeof(float);
+            const size_t need = (F * ((size_t)c->E + (size_t)n + (size_t)max_iters) + kNodesBarWords) * sizeof(float);
             if (c->ws_bytes < need) {
                 if (c->ws) {
                     LDPC_HIP(c, hipFree(c->ws));
@@ -558,13 +559,13 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             q.bar = (unsigned*)(q.synd_acc + F * (size_t)max_iters);
             c->nodes_bar = q.bar;
             q.hard = d_hard; q.out_iters = d_iters; q.out_synd = d_synd;
-            LDPC_HIP(c, hipMemsetAsync(q.synd_acc, 0, (F * (size_t)max_iters + 2) * sizeof(int32_t), s));
+            LDPC_HIP(c, hipMemsetAsync(q.synd_acc, 0, (F * (size_t)max_iters + kNodesBarWords) * sizeof(int32_t), s));
             NodesLaunch l;
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
                      : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
-            // the grid-wide barrier costs about 0.1 us per block, the phases shrink with the blocks they are
-            // spread over: measured optimum near 64 blocks for one frame, 128 for eight
-            l.max_blocks = std::min(c->nodes_blocks, 48 + 16 * (int)frames); l.stream = s;
+            // the grid-wide barrier grows with the blocks that meet in it, the phases shrink with the blocks they
+            // are spread over: measured optimum at 128 blocks (flat between 128 and 256) from 1 to 32 frames
+            l.max_blocks = std::min(c->nodes_blocks, 128); l.stream = s;
             if (c->opt.nodes_blocks)  // measurements: a smaller grid
                 l.max_blocks = std::max(1, std::min(c->nodes_blocks, c->opt.nodes_blocks));
             // tests: a grid of four times what can be resident, which the runtime must refuse at launch

@@ -43,7 +43,7 @@ for F in (1, 8, 32):
     ok &= run("C4 BG1-shaped Z=384 2 dB", bg, F, 50, True, 2.0)
 ok &= run("C4 BG1-shaped Z=384 1 dB", bg, 5, 12, False, 1.0)
 ok &= run("C4 BG1-shaped Z=384 0.5 dB", bg, 7, 30, True, 0.5)
-for F in (1, 4, 16, 32):
+for F in (1, 4, 8, 12, 16, 24, 32):
     ok &= run("C5 (3,6) n=64800 1.6 dB", c5, F, 50, True, 1.6)
 ok &= run("C5 (3,6) n=64800 1.0 dB", c5, 3, 20, True, 1.0)
 print("ALL IDENTICAL" if ok else "MISMATCH")
