@@ -147,22 +147,40 @@ __global__ void __launch_bounds__(256) gen_awgn_kernel(int n, float a, float b, 
 // Message bit i of a frame is bit (i & 127) of the Philox block (frame, i >> 7, stream 2).
 // A block encodes 64 frames at once, bit-sliced over the frames: U[i] holds message bit i of the 64 frames
 // in one 64-bit word, and the 64 code bits at position j are the XOR of U[i] over the ones of column j of
-// G.  GT[n][kw64] is G by columns, 64 rows to a word, so a position walks the set bits of its own column:
-// a column of the identity part of a systematic G costs one step, a parity column about k / 2, and every
-// step serves 64 frames (a frame-by-frame product reads all of G for every few frames).
-constexpr int kCwFrames = 64;   // frames per block
+// G.  The XOR is taken four message bits at a time: T[g][s], s = 0..15, is the XOR of the U words of
+// group g (message bits 4g .. 4g+3) selected by the bits of s, built once per block in LDS, and a position
+// looks up one entry per nibble of its column - k/4 branch-free steps instead of one step per set bit
+// (about k/2 in a parity column), each a 64-bit LDS read whose 64 lanes fall into 16 consecutive words
+// (no bank conflicts).  GT[kw64][n] is G by columns, 64 rows to a word, word-major, so that the lanes of a
+// wave (consecutive positions) read consecutive words; a zero word (most words of a column of the identity
+// part of a systematic G) is skipped.  T covers at most kCwWordsPerPass words of the columns at a time
+// (64 KiB); longer columns take several passes and rebuild it.
+constexpr int kCwFrames = 64;          // frames per block
+constexpr int kCwThreads = 1024;       // positions per round
+constexpr int kCwWordsPerPass = 32;    // 64-bit words of a column per table
 
-__global__ void __launch_bounds__(256) gen_codewords_kernel(int n, int k, const unsigned long long* GT, uint64_t seed,
-                                                            long long first_frame, long long frames, uint8_t* cw) {
+// bytes of dynamic LDS: U | T | stage, the raw message words of the first phase lie over T and stage
+__host__ __device__ inline size_t gen_codewords_lds_bytes(int k) {
+    const size_t kw32 = ((size_t)k + 31) >> 5, kw64 = ((size_t)k + 63) >> 6;
+    const size_t wp = kw64 < (size_t)kCwWordsPerPass ? kw64 : (size_t)kCwWordsPerPass;
+    const size_t tab = (wp * 256 + kCwThreads) * sizeof(unsigned long long);
+    const size_t raw = (size_t)kCwFrames * (kw32 | 1) * sizeof(uint32_t);
+    return kw64 * 64 * sizeof(unsigned long long) + (tab > raw ? tab : raw);
+}
+
+__global__ void __launch_bounds__(kCwThreads) gen_codewords_kernel(int n, int k, const unsigned long long* GT, uint64_t seed,
+                                                                   long long first_frame, long long frames, uint8_t* cw) {
     extern __shared__ unsigned long long cw_lds[];
     const int kw32 = (k + 31) >> 5, kw64 = (k + 63) >> 6, groups = (k + 127) >> 7;
+    const int wp = kw64 < kCwWordsPerPass ? kw64 : kCwWordsPerPass;
     const int raw_stride = kw32 | 1;                       // odd: the 64 lanes of a transposing read hit 64 banks
     unsigned long long* U = cw_lds;                        // [kw64 * 64] message bit i of the 64 frames
-    unsigned long long* stage = U + (size_t)kw64 * 64;     // [256] code bits of the positions in flight
-    uint32_t* raw = reinterpret_cast<uint32_t*>(stage + 256);   // [64][raw_stride] message words by frame
+    unsigned long long* T = U + (size_t)kw64 * 64;         // [wp * 16 groups][16] XOR combinations of a group
+    unsigned long long* stage = T + (size_t)wp * 256;      // [kCwThreads] code bits of the positions in flight
+    uint32_t* raw = reinterpret_cast<uint32_t*>(T);        // [64][raw_stride] message words by frame (first phase only)
     const long long f0 = (long long)blockIdx.x * kCwFrames;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int idx = threadIdx.x; idx < kCwFrames * groups; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < kCwFrames * groups; idx += kCwThreads) {
         const int fr = idx / groups, g = idx - fr * groups;
         const u32x4 x = frame_block(seed, (uint64_t)(first_frame + f0 + fr), (uint32_t)g, 2u);
         const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
@@ -170,32 +188,52 @@ __global__ void __launch_bounds__(256) gen_codewords_kernel(int n, int k, const 
             if (4 * g + q < kw32) raw[fr * raw_stride + 4 * g + q] = xs[q];
     }
     __syncthreads();
-    for (int i = wave; i < kw64 * 64; i += 4) {            // lane = frame: one ballot transposes bit i
+    for (int i = wave; i < kw64 * 64; i += kCwThreads / 64) {   // lane = frame: one ballot transposes bit i
         const bool bit = i < k && ((raw[lane * raw_stride + (i >> 5)] >> (i & 31)) & 1u);
         const unsigned long long mask = __ballot(bit);
         if (lane == 0) U[i] = mask;
     }
     __syncthreads();
-    for (int j0 = 0; j0 < n; j0 += 256) {
+    const bool one_pass = kw64 <= wp;
+    for (int j0 = 0; j0 < n; j0 += kCwThreads) {
         const int j = j0 + threadIdx.x;
         unsigned long long acc = 0ull;
-        if (j < n) {
-            const unsigned long long* col = GT + (size_t)j * kw64;
-            for (int w = 0; w < kw64; ++w) {
-                unsigned long long bits = col[w];
-                while (bits) {
-                    acc ^= U[w * 64 + __builtin_ctzll(bits)];
-                    bits &= bits - 1;
+        for (int w0 = 0; w0 < kw64; w0 += wp) {
+            const int words = (kw64 - w0 < wp) ? kw64 - w0 : wp;
+            if (!one_pass || j0 == 0) {
+                if (!one_pass) __syncthreads();            // the lookups of the previous pass are over
+                for (int e = threadIdx.x; e < words * 256; e += kCwThreads) {
+                    const unsigned long long* u = U + (size_t)w0 * 64 + 4 * (e >> 4);
+                    unsigned long long v = 0ull;
+                    if (e & 1) v ^= u[0];
+                    if (e & 2) v ^= u[1];
+                    if (e & 4) v ^= u[2];
+                    if (e & 8) v ^= u[3];
+                    T[e] = v;
+                }
+                __syncthreads();
+            }
+            if (j < n) {
+                for (int w = 0; w < words; ++w) {
+                    const unsigned long long bits = GT[(size_t)(w0 + w) * n + j];
+                    if (bits == 0ull) continue;
+                    const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+                    const unsigned long long* Tw = T + w * 256;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc ^= Tw[q * 16 + ((lo >> (4 * q)) & 15u)];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc ^= Tw[(8 + q) * 16 + ((hi >> (4 * q)) & 15u)];
                 }
             }
         }
         stage[threadIdx.x] = acc;
         __syncthreads();
         // bit fr of stage[p] -> byte cw[f0 + fr][j0 + p]: a wave writes 256 consecutive bytes of one frame
-        for (int fr = wave; fr < kCwFrames; fr += 4) {
+        for (int item = wave; item < kCwFrames * (kCwThreads / 256); item += kCwThreads / 64) {
+            const int fr = item / (kCwThreads / 256), p = (item % (kCwThreads / 256)) * 256 + 4 * lane;
             const long long f = f0 + fr;
             if (f >= frames) break;
-            const int p = 4 * lane;
+            if (j0 + p >= n) continue;
             uint8_t* o = cw + f * n + j0 + p;
             uint32_t b[4];
 #pragma unroll

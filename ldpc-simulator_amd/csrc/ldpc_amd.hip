@@ -816,13 +816,11 @@ int gen_codewords(ldpc_amd_ctx* c, uint64_t seed, long long first_frame, long lo
         LDPC_HIP(c, hipMemsetAsync(d_cw, 0, (size_t)frames * c->n, s));
         return LDPC_AMD_OK;
     }
-    const size_t kw32 = (size_t)(c->gen_k + 31) / 32, kw64 = (size_t)(c->gen_k + 63) / 64;
-    // U | stage | raw (see gen_codewords_kernel)
-    const size_t lds = (kw64 * 64 + 256) * sizeof(unsigned long long) + (size_t)kCwFrames * (kw32 | 1) * sizeof(uint32_t);
-    if (lds > 160 * 1024) return fail(c, LDPC_AMD_ELIMIT, "gen_codewords: generator matrices of more than about 13,000 rows are not supported");
+    const size_t lds = gen_codewords_lds_bytes(c->gen_k);
+    if (lds > 160 * 1024) return fail(c, LDPC_AMD_ELIMIT, "gen_codewords: generator matrices of more than 10,176 rows are not supported");
     auto kern = gen_codewords_kernel;
     LDPC_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)((frames + kCwFrames - 1) / kCwFrames)), dim3(256), lds, s, c->n, c->gen_k,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((frames + kCwFrames - 1) / kCwFrames)), dim3(kCwThreads), lds, s, c->n, c->gen_k,
                        c->d_gen, seed, first_frame, frames, d_cw);
     LDPC_HIP(c, hipGetLastError());
     return LDPC_AMD_OK;
@@ -1174,7 +1172,7 @@ int ldpc_amd_set_generator(ldpc_amd_ctx* c, int32_t k, const uint8_t* G) {
     std::vector<unsigned long long> packed((size_t)c->n * kw64, 0ull);
     for (int i = 0; i < k; ++i)
         for (int j = 0; j < c->n; ++j)
-            if (G[(size_t)i * c->n + j] & 1) packed[(size_t)j * kw64 + (i >> 6)] |= 1ull << (i & 63);
+            if (G[(size_t)i * c->n + j] & 1) packed[(size_t)(i >> 6) * c->n + j] |= 1ull << (i & 63);  // [kw64][n]
     LDPC_HIP(c, hipMalloc((void**)&c->d_gen, packed.size() * sizeof(unsigned long long)));
     LDPC_HIP(c, hipMemcpy(c->d_gen, packed.data(), packed.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     c->gen_k = k;

@@ -37,10 +37,13 @@ def test_codewords_bit_exact(sys_code, oracle):
 
 
 def test_codewords_odd_length(pkg, oracle):
-    """n not a multiple of 4, 32 or 256 and k not a multiple of 32, 64 or 128: the tail paths; dense G."""
+    """n not a multiple of 4, 32 or 256 and k not a multiple of 32, 64 or 128: the tail paths; dense G.
+    The last two shapes have columns of more than 32 words (k > 2048): the lookup tables are rebuilt per pass,
+    with a full last pass and with a short one."""
     import torch
     rng = np.random.default_rng(5)
-    for m, n, k, F in ((30, 75, 45, 19), (100, 301, 130, 70), (200, 777, 577, 130)):
+    for m, n, k, F in ((30, 75, 45, 19), (100, 301, 130, 70), (200, 777, 577, 130), (60, 2301, 2241, 70),
+                       (40, 1100, 4096, 65)):
         G = rng.integers(0, 2, (k, n)).astype(np.uint8)
         rows, cols = np.nonzero(rng.random((m, n)) < 0.1)
         dec = pkg.Decoder(m, n, rows, cols)
