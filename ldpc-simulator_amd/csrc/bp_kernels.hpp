@@ -65,6 +65,7 @@ struct BpParams {
     int32_t* out_iters;      // [frames_total] or null
     int32_t* out_synd;       // [frames_total] or null
     int lds_maxd;            // rows of LDS staging per wave and array (0 = no LDS path)
+    int bits_bytes;          // 1: a wave's share of a decision word is one or more whole bytes (8 variables), stored as bytes
 };
 
 // ---- vector access helpers: FPL consecutive floats / words per lane -------------------
@@ -709,6 +710,23 @@ __device__ __forceinline__ void cn_sweep(const BpParams& p, float* msg, const fl
     cn_rows_any<FPL, RULE, FIRST>(p, msg, lam, 0, p.m, lds, lane);
 }
 
+// Decision bits collected in acc go to the packed words when variable j closes a word, or closes a byte when
+// the variables of a word are shared out among several waves (small batches, bp_rows.hpp), or is the last one.
+template <int FPL>
+__device__ __forceinline__ void flush_decisions(const BpParams& p, uint32_t* bits, int j, uint32_t (&acc)[FPL]) {
+    const int mask = p.bits_bytes ? 7 : 31;
+    if ((j & mask) != mask && j != p.n - 1) return;
+    uint32_t* word = bits + (long long)(j >> 5) * p.bits_row;
+    if (p.bits_bytes) {
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) reinterpret_cast<uint8_t*>(word + f)[(j >> 3) & 3] = (uint8_t)(acc[f] >> (j & 24));
+    } else {
+        stw<FPL>(word, acc);
+    }
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) acc[f] = 0u;
+}
+
 // beta for the next iteration + tentative decisions of this one (LogDecoder.java:67-79, :98-105)
 template <int FPL, int D>
 struct VnBuf {
@@ -743,11 +761,7 @@ __device__ __forceinline__ void vn_finish(const BpParams& p, float* msg, uint32_
     }
 #pragma unroll
     for (int f = 0; f < FPL; ++f) acc[f] |= (g[f] < 0.0f ? 1u : 0u) << (j & 31);  // "(gamma[j] < 0) ? 1 : 0", :104
-    if ((j & 31) == 31 || j == p.n - 1) {
-        stw<FPL>(bits + (long long)(j >> 5) * p.bits_row, acc);
-#pragma unroll
-        for (int f = 0; f < FPL; ++f) acc[f] = 0u;
-    }
+    flush_decisions<FPL>(p, bits, j, acc);
 }
 
 template <int FPL, int D>
@@ -769,7 +783,7 @@ __device__ __forceinline__ void vn_sweep_regular(const BpParams& p, float* msg, 
     if (j < n) vn_finish<FPL, D>(p, msg, bits, j, write_beta, A, acc);
 }
 
-// Any degrees: variables j0 .. j1-1 (j0 a multiple of 32, acc the decision bits collected so far), with runs
+// Any degrees: variables j0 .. j1-1 (j0 a multiple of 32, or of 8 with bits_bytes; acc the decision bits collected so far), with runs
 // of one degree grouped like the checks in cn_rows_any.
 template <int FPL, int D>
 __device__ __forceinline__ int vn_run(const BpParams& p, float* msg, const float* lam, uint32_t* bits, bool write_beta,
@@ -825,11 +839,7 @@ __device__ __forceinline__ void vn_cols_any(const BpParams& p, float* msg, const
                          p.lds_maxd, lane);
 #pragma unroll
         for (int f = 0; f < FPL; ++f) acc[f] |= (g[f] < 0.0f ? 1u : 0u) << (j & 31);  // "(gamma[j] < 0) ? 1 : 0", :104
-        if ((j & 31) == 31 || j == p.n - 1) {
-            stw<FPL>(bits + (long long)(j >> 5) * p.bits_row, acc);
-#pragma unroll
-            for (int f = 0; f < FPL; ++f) acc[f] = 0u;
-        }
+        flush_decisions<FPL>(p, bits, j, acc);
         ++j;
     }
 }

@@ -28,13 +28,14 @@ hipError_t run(const RowsLaunch& l, RowsParams p) {
     const dim3 block((unsigned)(64 * l.wpb));
     const dim3 grid((unsigned)((l.chunks + l.wpb - 1) / l.wpb), (unsigned)p.b.tiles);
     const int slots = p.b.tiles * kWave * FPL;
+    p.slots = slots;
     const dim3 sgrid((unsigned)((slots + 255) / 256));
     for (int it = 0; it < p.b.max_iters; ++it) {
         p.iter = it;
         const bool last = it + 1 == p.b.max_iters;
         launch_cn<FPL, DC>(l, p, grid, block, it == 0);
         hipLaunchKernelGGL((rows_vn_kernel<FPL, DV>), grid, block, l.lds_bytes, l.stream, p, (p.early || !last) ? 1 : 0);
-        if (p.early || last) {
+        if (last) {  // with early termination the launches above carry the syndrome of the iteration before
             hipLaunchKernelGGL((rows_synd_kernel<FPL>), grid, block, 0, l.stream, p);
             hipLaunchKernelGGL(rows_finish_kernel, sgrid, dim3(256), 0, l.stream, p, slots, last ? 1 : 0);
         }

@@ -7,6 +7,15 @@
 // the grid-wide barrier between the CN and the VN sweep -- on the same frame-major arrays and with the
 // same per-row code (cn_dispatch / vn_dispatch of bp_kernels.hpp), so the bits are identical to the
 // one-launch kernel's.  Per-frame early termination lives in small state arrays between launches.
+//
+// Early termination costs no launch of its own: the syndrome of the decisions of iteration l-1
+// (LogDecoder.java:108-116) is formed by the check-node launch of iteration l, whose waves walk the same
+// rows anyway, into the accumulator of parity (l-1) & 1; the variable-node launch of iteration l, which
+// starts after that launch has ended, reads the complete weights: a frame whose weight is 0 had converged
+// at iteration l-1, its lanes sit out from here on and its decisions stay as that iteration left them
+// (the check-node update its messages have just received is never used).  The first wave of every tile
+// records that (done, l, weight 0) and clears the other accumulator for the next iteration.  Only after
+// the last iteration do the syndrome and the closing launch run on their own.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,7 +31,8 @@ struct RowsParams {
     int iter;            // iteration this launch belongs to (0-based)
     int early;           // per-frame early termination
     int32_t* st_done;    // [tiles*T] 0 = still iterating (early mode)
-    int32_t* st_acc;     // [tiles*T] syndrome weight accumulator of the current iteration
+    int32_t* st_acc;     // [2][slots] syndrome weight accumulators, by parity of the iteration they belong to
+    int slots;           // tiles * T
     int32_t* st_iters;   // [tiles*T]
     int32_t* st_synd;    // [tiles*T]
 };
@@ -34,6 +44,49 @@ __device__ __forceinline__ bool rows_lane_active(const RowsParams& p, int tile, 
     // FPL > 1 only runs without early termination; with FPL == 1 a finished frame's lane sits out
     if constexpr (FPL == 1) return !p.early || p.st_done[(long long)tile * kWave + lane] == 0;
     return true;
+}
+
+// number of unsatisfied checks among rows i0 .. i1-1 of the packed decisions (sumSyndro, LogDecoder.java:108-116)
+template <int FPL>
+__device__ __forceinline__ void rows_syndrome(const BpParams& b, const uint32_t* bits, int i0, int i1, int (&w)[FPL]) {
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) w[f] = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int e0 = b.row_ptr[i], e1 = b.row_ptr[i + 1];
+        uint32_t par[FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) par[f] = 0u;
+        int e = e0;
+        for (; e + 8 <= e1; e += 8) {  // eight loads in flight: the row is a chain of cache hits otherwise
+            int j[8];
+            uint32_t v[8][FPL];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) j[u] = b.edge_col[e + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ldw<FPL>(bits + (long long)(j[u] >> 5) * b.bits_row, v[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int f = 0; f < FPL; ++f) par[f] ^= v[u][f] >> (j[u] & 31);
+        }
+        if (e < e1) {  // the rest of the row, again all at once
+            int j[8];
+            uint32_t v[8][FPL];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) j[u] = (e + u < e1) ? b.edge_col[e + u] : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j[u] >= 0) ldw<FPL>(bits + (long long)(j[u] >> 5) * b.bits_row, v[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j[u] >= 0) {
+#pragma unroll
+                    for (int f = 0; f < FPL; ++f) par[f] ^= v[u][f] >> (j[u] & 31);
+                }
+        }
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) w[f] += (int)(par[f] & 1u);
+    }
 }
 
 // A wave's rows are handled in groups whose loads are all issued before the first of them is used
@@ -54,6 +107,13 @@ __global__ void __launch_bounds__(256, 4) rows_cn_kernel(RowsParams p) {
     float* msg = p.b.ws_msg + (long long)tile * p.b.msg_tile + lane * FPL;
     const float* lam = p.b.ws_lam + (long long)tile * p.b.lam_tile + lane * FPL;
     if (rows_lane_active<FPL>(p, tile, lane)) {
+        if constexpr (FPL == 1 && !FIRST) {
+            if (p.early) {  // weight of the previous iteration's syndrome over this wave's rows
+                int w[1];
+                rows_syndrome<1>(p.b, p.b.ws_bits + (long long)tile * p.b.bits_tile + lane, i0, i1, w);
+                if (w[0]) atomicAdd(&p.st_acc[(long long)((p.iter - 1) & 1) * p.slots + (long long)tile * kWave + lane], w[0]);
+            }
+        }
         if constexpr (DC > 0) {
             constexpr int G = rows_group<FPL, DC>();
             for (int i = i0; i < i1; i += G) {
@@ -84,7 +144,26 @@ __global__ void __launch_bounds__(256, 4) rows_vn_kernel(RowsParams p, int write
     float* msg = p.b.ws_msg + (long long)tile * p.b.msg_tile + lane * FPL;
     const float* lam = p.b.ws_lam + (long long)tile * p.b.lam_tile + lane * FPL;
     uint32_t* bits = p.b.ws_bits + (long long)tile * p.b.bits_tile + lane * FPL;
-    if (!rows_lane_active<FPL>(p, tile, lane)) return;
+    bool active = rows_lane_active<FPL>(p, tile, lane);
+    if constexpr (FPL == 1) {
+        if (p.early && p.iter > 0) {
+            // the check-node launch of this iteration has left the weight of the previous iteration's syndrome
+            const long long slot = (long long)tile * kWave + lane;
+            const int w = p.st_acc[(long long)((p.iter - 1) & 1) * p.slots + slot];
+            if (chunk == 0) {  // one wave per tile keeps the books
+                if (active) {
+                    p.st_synd[slot] = w;
+                    if (w == 0) {  // "if(sumSyndro == 0) return ... l + 1", LogDecoder.java:117-119
+                        p.st_done[slot] = 1;
+                        p.st_iters[slot] = p.iter;
+                    }
+                }
+                p.st_acc[(long long)(p.iter & 1) * p.slots + slot] = 0;  // last read one launch pair ago
+            }
+            active = active && w != 0;
+        }
+    }
+    if (!active) return;
     uint32_t acc[FPL];
 #pragma unroll
     for (int f = 0; f < FPL; ++f) acc[f] = 0u;
@@ -115,40 +194,11 @@ __global__ void __launch_bounds__(256, 4) rows_synd_kernel(RowsParams p) {
     const uint32_t* bits = p.b.ws_bits + (long long)tile * p.b.bits_tile + lane * FPL;
     if (!rows_lane_active<FPL>(p, tile, lane)) return;
     int w[FPL];
-#pragma unroll
-    for (int f = 0; f < FPL; ++f) w[f] = 0;
-    for (int i = i0; i < i1; ++i) {
-        const int e0 = p.b.row_ptr[i], e1 = p.b.row_ptr[i + 1];
-        uint32_t par[FPL];
-#pragma unroll
-        for (int f = 0; f < FPL; ++f) par[f] = 0u;
-        int e = e0;
-        for (; e + 4 <= e1; e += 4) {  // four loads in flight: the row is a chain of cache hits otherwise
-            int j[4];
-            uint32_t v[4][FPL];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                j[u] = p.b.edge_col[e + u];
-                ldw<FPL>(bits + (long long)(j[u] >> 5) * p.b.bits_row, v[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int f = 0; f < FPL; ++f) par[f] ^= v[u][f] >> (j[u] & 31);
-        }
-        for (; e < e1; ++e) {
-            const int j = p.b.edge_col[e];
-            uint32_t v[FPL];
-            ldw<FPL>(bits + (long long)(j >> 5) * p.b.bits_row, v);
-#pragma unroll
-            for (int f = 0; f < FPL; ++f) par[f] ^= v[f] >> (j & 31);
-        }
-#pragma unroll
-        for (int f = 0; f < FPL; ++f) w[f] += (int)(par[f] & 1u);
-    }
+    rows_syndrome<FPL>(p.b, bits, i0, i1, w);
+    int32_t* acc = p.st_acc + (long long)(p.iter & 1) * p.slots + (long long)tile * (kWave * FPL) + lane * FPL;
 #pragma unroll
     for (int f = 0; f < FPL; ++f)
-        if (w[f]) atomicAdd(&p.st_acc[(long long)tile * (kWave * FPL) + lane * FPL + f], w[f]);
+        if (w[f]) atomicAdd(&acc[f], w[f]);
 }
 
 // one thread per frame slot: close the iteration (LogDecoder.java:115-119)
@@ -156,8 +206,7 @@ __global__ void __launch_bounds__(256) rows_finish_kernel(RowsParams p, int slot
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= slots) return;
     if (p.early && p.st_done[s]) return;
-    const int w = p.st_acc[s];
-    p.st_acc[s] = 0;
+    const int w = p.st_acc[(long long)(p.iter & 1) * p.slots + s];
     p.st_synd[s] = w;
     if (p.early && w == 0) {
         p.st_done[s] = 1;

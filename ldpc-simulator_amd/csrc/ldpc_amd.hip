@@ -391,7 +391,7 @@ void note_nodes_refusal(ldpc_amd_ctx* c, hipError_t e, int blocks, bool retrying
 
 // Bytes of streaming workspace one tile of T frames takes: messages, LLRs, packed decisions, 4 state words.
 size_t stream_tile_bytes(const ldpc_amd_ctx* c, int T) {
-    return ((size_t)c->E + (size_t)c->n + (size_t)c->nw + 4) * (size_t)T * sizeof(float);
+    return ((size_t)c->E + (size_t)c->n + (size_t)c->nw + 5) * (size_t)T * sizeof(float);
 }
 
 // noalloc: run the sweep launches on the static scratch array and call nothing that allocates.
@@ -520,11 +520,13 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
                          c->nodes_blocks >= 0 && c->opt.engine != LDPC_AMD_ENGINE_STREAM;
         bool use = can;
         // Per iteration this engine costs two grid barriers and the latency of two dependent phases (about
-        // 14 us together) plus about 45 ns per 1000 edges of the batch (gathers of single words); the sweep
-        // launches cost about 100 us of launches plus the longest wave's chain of dependent nodes, 32
-        // variables of the largest degree (measured on an NR-BG1-sized code and on a (3,6) code of n = 64800:
-        // break-even beyond 32 frames and near 10 frames).
-        use = use && 14.0 + 4.5e-5 * (double)frames * (double)c->E < 100.0 + 5.8 * c->max_dv;
+        // 14 us together) plus about 45 ns per 1000 edges of the batch (gathers of single words); the sweeps
+        // cost two launches of short waves: about 80 us with the kernels specialised for a regular code, and
+        // 70 us plus a round trip per variable of the largest degree otherwise (measured on an NR-BG1-sized
+        // code and on a (3,6) code of n = 64800: break-even near 20 and near 9 frames).
+        const bool specialised_rows = (c->reg_dc == 6 && c->reg_dv == 3) || (c->reg_dc == 8 && c->reg_dv == 2);
+        const double sweeps_us = specialised_rows ? 80.0 : 70.0 + 0.9 * c->max_dv;
+        use = use && 14.0 + 4.5e-5 * (double)frames * (double)c->E < sweeps_us;
         if (c->opt.nodes >= 0) use = can && c->opt.nodes != 0;  // 0: never, 1: whenever the batch and the degrees allow
         if (use && c->nodes_blocks == 0) {
             int coop = 0, blocks = 0;
@@ -615,7 +617,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     size_t lds_bytes = use_lds ? (size_t)2 * lds_maxd * 64 * sizeof(float) : 0;
 
     const long long tiles_total = (frames + T - 1) / T;
-    // + 4 words of per-frame state for the row-parallel launches
+    // + 5 words of per-frame state for the row-parallel launches
     const size_t per_tile = stream_tile_bytes(c, T);
     unsigned long long limit = noalloc ? (unsigned long long)LDPC_AMD_NOALLOC_SCRATCH_BYTES : c->ws_limit;
     if (!limit) {
@@ -691,10 +693,28 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     int chunks = 1, rows_per_chunk = c->m, vars_per_chunk = (n + 31) / 32 * 32;
     if (by_rows) {
         chunks = std::max(1, std::min(4096, std::min(c->m / 4, n / 32)));
-        if (c->opt.rows_waves)  // measurements: waves per launch
-            chunks = (int)std::max<long long>(1, std::min<long long>(chunks, (std::max(256, c->opt.rows_waves) + tiles_per_round - 1) / tiles_per_round));
+        // A small batch has few tiles, and a wave's rows are a chain of dependent memory round trips (in the
+        // any-degree kernels a node of degree above 12 is a round trip of its own): with fewer than `want`
+        // waves in a launch the rows of such a code are cut finer, down to 2 checks and 8 variables per wave
+        // (NR-BG1-sized code, 64 frames: 119 -> 43 us per iteration, 512 frames: 306 -> 234; from 2048 frames
+        // on the coarse cut is as good or better).  Eight variables share a byte of the packed decisions,
+        // which such a wave stores as a byte; cuts between 17 and 31 variables measured far slower than
+        // either neighbour and are not used.  The kernels specialised for a regular code issue the loads of
+        // several rows together and lose by a finer cut.
+        const bool specialised = (c->reg_dc == 6 && c->reg_dv == 3) || (c->reg_dc == 8 && c->reg_dv == 2);
+        long long want = 32768;
+        if (c->opt.rows_waves) want = std::max(256, c->opt.rows_waves);  // measurements: waves per launch
+        if (c->opt.rows_waves && (long long)chunks * tiles_per_round > want)
+            chunks = (int)std::max<long long>(1, (want + tiles_per_round - 1) / tiles_per_round);
+        if (fpl == 1 && !specialised && (long long)chunks * tiles_per_round < want) {
+            const long long finest = std::max(1, std::min(c->m / 2, n / 8));
+            const long long finer = std::min<long long>((want + tiles_per_round - 1) / tiles_per_round, finest);
+            if (finer >= (n + 15) / 16) chunks = (int)std::max<long long>(chunks, finer);
+        }
         rows_per_chunk = (c->m + chunks - 1) / chunks;
-        vars_per_chunk = ((n + chunks - 1) / chunks + 31) / 32 * 32;
+        const int unit = (fpl == 1 && chunks > n / 32) ? 8 : 32;  // variables that share a stored byte / word
+        vars_per_chunk = ((n + chunks - 1) / chunks + unit - 1) / unit * unit;
+        p.bits_bytes = unit == 8 ? 1 : 0;
         c->last_kernel = "rows_cn_kernel";
         use_lds = c->max_dc > kRowsRegDegCn || c->max_dv > kRowsRegDegVn;
         lds_maxd = use_lds ? maxdeg : 0;
@@ -731,8 +751,8 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             q.vars_per_chunk = vars_per_chunk;
             q.early = early ? 1 : 0;
             const size_t slots = (size_t)tiles * T;
-            q.st_done = ws_state; q.st_acc = ws_state + slots; q.st_iters = ws_state + 2 * slots; q.st_synd = ws_state + 3 * slots;
-            LDPC_HIP(c, hipMemsetAsync(ws_state, 0, 4 * slots * sizeof(int32_t), s));
+            q.st_done = ws_state; q.st_iters = ws_state + slots; q.st_synd = ws_state + 2 * slots; q.st_acc = ws_state + 3 * slots;
+            LDPC_HIP(c, hipMemsetAsync(ws_state, 0, 5 * slots * sizeof(int32_t), s));
             RowsLaunch l;
             l.fpl = fpl == 4 ? 4 : 1;
             l.dc = c->reg_dc; l.dv = c->reg_dv;  // 0 for an irregular code

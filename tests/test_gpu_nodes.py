@@ -117,3 +117,31 @@ def test_refused_cooperative_launch_is_observable_and_not_final(pkg):
     for x, y in zip(again, want):
         assert (x == y).all()
     dec.close()
+
+
+def test_row_chunking_of_small_batches_does_not_change_a_bit(pkg, oracle):
+    """A small batch of a code the specialised kernels do not take is cut into short waves, down to 8 variables
+    each, which store their share of a packed decision word as bytes: every cut returns the words of the
+    double oracle, on a length that is no multiple of 8 as well."""
+    rng = np.random.default_rng(11)
+    _, bg = pkg.codes.nr_bg1_shaped(z=8, seed=3)
+    m2, n2 = 150, 301
+    H = (rng.random((m2, n2)) < 0.02).astype(np.uint8)
+    H[np.arange(m2), rng.integers(0, n2, m2)] = 1
+    H[rng.integers(0, m2, n2), np.arange(n2)] = 1
+    r2, c2 = np.nonzero(H)
+    for (m, n, rows, cols), F in ((bg, 70), ((m2, n2, r2.astype(np.int32), c2.astype(np.int32)), 130)):
+        g = oracle.Graph(m, n, rows, cols)
+        dec = pkg.Decoder(m, n, rows, cols)
+        dec.set_option("engine", "stream")
+        dec.set_option("nodes", 0)
+        llr = oracle.gen_awgn_llr(m, n, 2.5, seed=9, first_frame=0, frames=F)
+        for early, L in ((True, 30), (False, 5)):
+            want = g.decode_llr_batch(llr, L, early)
+            for waves in (0, 256, 1024, 4096, 1 << 20):
+                dec.set_option("rows_waves", waves)
+                got = dec.decode_batch(llr, L, early)
+                assert dec.last_decode_kernel() == "rows_cn_kernel"
+                for x, y in zip(got, want):
+                    assert (x == y).all(), (n, early, waves)
+        dec.close()
