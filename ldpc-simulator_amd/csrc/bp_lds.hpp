@@ -30,6 +30,8 @@ struct LdsParams {
     const int* perm;       // [n]  variable handled at VN position p (thread p % nt, step p / nt)
     const int* pos_of_var; // [n]  inverse of perm
     const int* vn_off;     // [n*DV] byte offset in msg of edge k of the variable at position p, [p*DV + k]
+    const uint32_t* tog;   // [(kLdsVpt/2)*DV][nt] syndrome bit of the check on edge k of the variables at positions
+                           // t + v*nt (low half) and t + (v+1)*nt (high half), v even, at [(v/2*DV + k)*nt + t]
     const float* llr;      // [frames][n] channel LLRs, or null
     const uint8_t* r;      // [frames][n] hard received words (then lambda = +-l0 / +-l1), or null
     float l0, l1;          // already in the rule's LLR unit
@@ -74,7 +76,6 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
 
     // LDS addresses of the edge slots of this thread's variables: fixed for the whole decode, and
     // kept opaque so that they stay in registers instead of being re-formed as base + offset per use
-    const uint32_t lds_base = lds_address(msgb);
     uint32_t off[kLdsVpt][DV];
 #pragma unroll
     for (int v = 0; v < kLdsVpt; ++v)
@@ -126,19 +127,23 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
     __syncthreads();
 
     // toggles the syndrome bits of the checks of those of this thread's variables whose bit is set in
-    // `which` (static indices into off[][]: a run-time index would move the array to scratch memory)
+    // `which`.  The bit numbers come from a table (12 coalesced words per lane, read when a toggle is due,
+    // from a 24 KiB array that every workgroup shares): deriving them from the slot addresses cost a division
+    // by 2*DC per edge and made the first iterations, where most lanes toggle, twice as long as the later ones.
     auto toggle_checks = [&](uint32_t which) {
+        const uint32_t* tog = p.tog + t;
+        asm volatile("" : "+v"(tog));  // read here, when needed: 12 more loop invariants do not fit
+        uint32_t x[kLdsVpt / 2][DV];
+#pragma unroll
+        for (int h = 0; h < kLdsVpt / 2; ++h)
+#pragma unroll
+            for (int k = 0; k < DV; ++k) x[h][k] = tog[(h * DV + k) * nt];
 #pragma unroll
         for (int v = 0; v < kLdsVpt; ++v) {
             if ((which >> v) & 1u) {
 #pragma unroll
                 for (int k = 0; k < DV; ++k) {
-                    // slot -> syndrome bit: 2 * (pair row) + (which check of the pair); any fixed
-                    // one-to-one numbering of the checks serves
-                    uint32_t o = off[v][k];
-                    asm volatile("" : "+v"(o));  // formed here, when needed: 24 more loop invariants do not fit
-                    const uint32_t slot = (o - lds_base) >> 2;
-                    const uint32_t b = 2u * (slot / (2u * DC)) + (slot & 1u);
+                    const uint32_t b = (v & 1) ? (x[v / 2][k] >> 16) : (x[v / 2][k] & 0xffffu);
                     atomicXor(&par[b >> 5], 1u << (b & 31u));
                 }
             }
