@@ -30,8 +30,6 @@ struct LdsParams {
     const int* perm;       // [n]  variable handled at VN position p (thread p % nt, step p / nt)
     const int* pos_of_var; // [n]  inverse of perm
     const int* vn_off;     // [n*DV] byte offset in msg of edge k of the variable at position p, [p*DV + k]
-    const uint32_t* tog;   // [(kLdsVpt/2)*DV][nt] syndrome bit of the check on edge k of the variables at positions
-                           // t + v*nt (low half) and t + (v+1)*nt (high half), v even, at [(v/2*DV + k)*nt + t]
     const float* llr;      // [frames][n] channel LLRs, or null
     const uint8_t* r;      // [frames][n] hard received words (then lambda = +-l0 / +-l1), or null
     float l0, l1;          // already in the rule's LLR unit
@@ -76,6 +74,7 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
 
     // LDS addresses of the edge slots of this thread's variables: fixed for the whole decode, and
     // kept opaque so that they stay in registers instead of being re-formed as base + offset per use
+    const uint32_t lds_base = lds_address(msgb);
     uint32_t off[kLdsVpt][DV];
 #pragma unroll
     for (int v = 0; v < kLdsVpt; ++v)
@@ -89,14 +88,6 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
     // iterations.  At fixed iterations it takes one frame (the launch gives it no second one), and the
     // compiler sees a body that runs once and keeps nothing else alive across it.
     for (long long frame = blockIdx.x; frame < p.frames; frame += gridDim.x) {
-    // channel LLR of variable j of this frame (LogDecoder.java:49-54 for a hard received word)
-    const float* src_llr = p.llr ? p.llr + frame * p.n : nullptr;
-    const uint8_t* src_r = p.r ? p.r + frame * p.n : nullptr;
-    auto lam_of = [&](int j) -> float {
-        if (src_llr) return src_llr[j] * p.scale;
-        const float mag = (j < p.g_length) ? p.l0 : p.l1;
-        return (src_r[j] == 0) ? mag : -mag;
-    };
     if (t == 0) *red = 0;
     // The syndrome is kept as one bit per check.  With early termination it is maintained every iteration
     // by toggling the checks of the variables whose decision changed since the previous one (few, after
@@ -107,11 +98,41 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
     for (int w = t; w < mw; w += nt) par[w] = 0u;
     uint32_t mydec = 0u;  // bit v: the current decision of this thread's variable v
 
-    // channel LLRs of this thread's own variables stay in registers for the whole decode
+    // Channel LLRs of this thread's own variables (LogDecoder.java:49-54 for a hard received word); they stay
+    // in registers for the whole decode.  The eight table reads go out together and so do the eight gathers
+    // that depend on them: two memory round trips per frame (one branch per variable made it sixteen, each
+    // waited for in turn, and that was most of what a frame cost beyond its iterations).  tt: the per-frame
+    // address arithmetic is kept inside the frame loop, where its registers are free again afterwards.
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    float lam8[kLdsVpt];
+    {
+        const int* permp = p.perm + tt;
+        int pj[kLdsVpt];
+#pragma unroll
+        for (int v = 0; v < kLdsVpt; ++v) pj[v] = permp[v * nt];
+        if (p.llr) {
+            const float* src_llr = p.llr + frame * p.n;
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; ++v) lam8[v] = src_llr[pj[v]];
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; ++v) lam8[v] *= p.scale;
+        } else {
+            const uint8_t* src_r = p.r + frame * p.n;
+            uint8_t rb[kLdsVpt];
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; ++v) rb[v] = src_r[pj[v]];
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; ++v) {
+                const float mag = (pj[v] < p.g_length) ? p.l0 : p.l1;
+                lam8[v] = (rb[v] == 0) ? mag : -mag;
+            }
+        }
+    }
     v2f vl[kLdsVpt / 2];
 #pragma unroll
     for (int v = 0; v < kLdsVpt; v += 2) {
-        float a = lam_of(p.perm[t + v * nt]), b = lam_of(p.perm[t + (v + 1) * nt]);
+        float a = lam8[v], b = lam8[v + 1];
         asm volatile("" : "+v"(a), "+v"(b));  // loaded once, here
         vl[v / 2] = v2f{a, b};
     }
@@ -127,23 +148,19 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
     __syncthreads();
 
     // toggles the syndrome bits of the checks of those of this thread's variables whose bit is set in
-    // `which`.  The bit numbers come from a table (12 coalesced words per lane, read when a toggle is due,
-    // from a 24 KiB array that every workgroup shares): deriving them from the slot addresses cost a division
-    // by 2*DC per edge and made the first iterations, where most lanes toggle, twice as long as the later ones.
+    // `which` (static indices into off[][]: a run-time index would move the array to scratch memory)
     auto toggle_checks = [&](uint32_t which) {
-        const uint32_t* tog = p.tog + t;
-        asm volatile("" : "+v"(tog));  // read here, when needed: 12 more loop invariants do not fit
-        uint32_t x[kLdsVpt / 2][DV];
-#pragma unroll
-        for (int h = 0; h < kLdsVpt / 2; ++h)
-#pragma unroll
-            for (int k = 0; k < DV; ++k) x[h][k] = tog[(h * DV + k) * nt];
 #pragma unroll
         for (int v = 0; v < kLdsVpt; ++v) {
             if ((which >> v) & 1u) {
 #pragma unroll
                 for (int k = 0; k < DV; ++k) {
-                    const uint32_t b = (v & 1) ? (x[v / 2][k] >> 16) : (x[v / 2][k] & 0xffffu);
+                    // slot -> syndrome bit: 2 * (pair row) + (which check of the pair); any fixed
+                    // one-to-one numbering of the checks serves
+                    uint32_t o = off[v][k];
+                    asm volatile("" : "+v"(o));  // formed here, when needed: 24 more loop invariants do not fit
+                    const uint32_t slot = (o - lds_base) >> 2;
+                    const uint32_t b = 2u * (slot / (2u * DC)) + (slot & 1u);
                     atomicXor(&par[b >> 5], 1u << (b & 31u));
                 }
             }
@@ -218,14 +235,20 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
             __syncthreads();
         }
     }
-    // decisions -> packed words by VN position (q is a multiple of 64 in lane 0, n a multiple of 64)
+    // decisions -> packed words by VN position: position t + v*nt of lane 0 of a wave is a multiple of 64, so its
+    // word is (t >> 5) + v * (nt >> 5)
+    {
+        unsigned long long mask[kLdsVpt];
 #pragma unroll
-    for (int v = 0; v < kLdsVpt; ++v) {
-        const unsigned long long mask = __ballot((mydec >> v) & 1u);
-        if ((t & 63) == 0) {
-            const int q = t + v * nt;
-            bits[q >> 5] = (uint32_t)mask;
-            bits[(q >> 5) + 1] = (uint32_t)(mask >> 32);
+        for (int v = 0; v < kLdsVpt; ++v) mask[v] = __ballot((mydec >> v) & 1u);
+        if ((tt & 63) == 0) {
+            uint32_t* b0 = bits + (tt >> 5);
+            const int step = nt >> 5;
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; ++v) {
+                b0[v * step] = (uint32_t)mask[v];
+                b0[v * step + 1] = (uint32_t)(mask[v] >> 32);
+            }
         }
     }
     __syncthreads();
@@ -243,19 +266,14 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
         synd = *red;
     }
 
-    uint8_t* out = p.hard + frame * p.n;
-    if ((p.n & 3) == 0) {
-        for (int j4 = t; j4 < (p.n >> 2); j4 += nt) {
-            const int4 q = reinterpret_cast<const int4*>(p.pos_of_var)[j4];
-            reinterpret_cast<uchar4*>(out)[j4] =
-                make_uchar4((bits[q.x >> 5] >> (q.x & 31)) & 1u, (bits[q.y >> 5] >> (q.y & 31)) & 1u,
-                            (bits[q.z >> 5] >> (q.z & 31)) & 1u, (bits[q.w >> 5] >> (q.w & 31)) & 1u);
-        }
-    } else {
-        for (int j = t; j < p.n; j += nt) {
-            const int q = p.pos_of_var[j];
-            out[j] = (uint8_t)((bits[q >> 5] >> (q & 31)) & 1u);
-        }
+    // hard[frame][j] for j = 4 tt .. 4 tt + 3 and 4 (tt + nt) .. : n = 8 nt, both table reads go out together
+    {
+        uint8_t* out = p.hard + frame * p.n;
+        const int4* pos4 = reinterpret_cast<const int4*>(p.pos_of_var) + tt;
+        const int4 q0 = pos4[0], q1 = pos4[nt];
+        auto bit = [&](int q) -> unsigned char { return (unsigned char)((bits[q >> 5] >> (q & 31)) & 1u); };
+        reinterpret_cast<uchar4*>(out)[tt] = make_uchar4(bit(q0.x), bit(q0.y), bit(q0.z), bit(q0.w));
+        reinterpret_cast<uchar4*>(out)[tt + nt] = make_uchar4(bit(q1.x), bit(q1.y), bit(q1.z), bit(q1.w));
     }
     if (t == 0) {
         if (p.out_iters) p.out_iters[frame] = iters;

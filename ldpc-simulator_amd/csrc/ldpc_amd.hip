@@ -69,7 +69,7 @@ struct ldpc_amd_ctx {
     size_t stage_cw_bytes = 0;
     // tables of the frame-resident engine (built on first use, see build_resident_tables)
     int res_nt = 0;
-    int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E] | tog[E/2]
+    int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E]
     double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
     // tables of the generic frame-resident engine: cn_desc | vn_desc | pos_of_var[n] | edge_pos[E] | edge_slot[E] | col_slot[E] | col_check[E]
     int gen_nt = 0, gen_cn_steps = 0, gen_vn_steps = 0, gen_slots = 0;
@@ -244,24 +244,14 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt) {
     c->res_conflict = mult_cnt ? (double)mult_sum / (double)mult_cnt : 1.0;
     // layout: perm[n] (variable at each position) | pos[n] (position of each variable) | vn_off[E] (byte
     // offsets of the edge slots of the variable at each position)
-    // | tog[E/2] (syndrome bit numbers of the checks on those edges, two positions to a word: bp_lds.hpp)
-    std::vector<int> tab((size_t)(2 * n) + (size_t)E + (size_t)E / 2, 0);
+    std::vector<int> tab((size_t)(2 * n) + (size_t)E);
     int* t_perm = tab.data();
     int* t_pos = t_perm + n;
     int* t_vn = t_pos + n;
-    int* t_tog = t_vn + E;
     for (int p = 0; p < n; ++p) {
         t_perm[p] = perm[(size_t)p];
         t_pos[p] = pos[(size_t)p];
-        const int t = p % nt, v = p / nt;
-        for (int k = 0; k < dv; ++k) {
-            const int sl = slot[(size_t)c->h_col_edge[(size_t)perm[(size_t)p] * dv + k]];
-            t_vn[(size_t)p * dv + k] = 4 * sl;
-            // syndrome bit of the check that owns the slot: 2 * (pair row) + (which check of the pair); any
-            // fixed one-to-one numbering of the checks serves
-            const unsigned bit = 2u * (unsigned)(sl / (2 * dc)) + (unsigned)(sl & 1);
-            t_tog[(size_t)((v / 2) * dv + k) * nt + t] |= (int)(bit << (16 * (v & 1)));
-        }
+        for (int k = 0; k < dv; ++k) t_vn[(size_t)p * dv + k] = 4 * slot[(size_t)c->h_col_edge[(size_t)perm[(size_t)p] * dv + k]];
     }
     if (c->d_res) {
         LDPC_HIP(c, hipFree(c->d_res));
@@ -434,7 +424,6 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             LdsParams q{};
             q.m = c->m; q.n = n; q.nw = c->nw; q.E = c->E;
             q.perm = c->d_res; q.pos_of_var = q.perm + n; q.vn_off = q.pos_of_var + n;
-            q.tog = reinterpret_cast<const uint32_t*>(q.vn_off + c->E);
             q.llr = src.kind == Src::Float ? src.llr : nullptr;
             q.r = src.kind == Src::Bsc ? src.r : nullptr;
             q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
