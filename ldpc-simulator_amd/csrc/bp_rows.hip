@@ -12,9 +12,12 @@ namespace {
 
 template <int FPL, int DC>
 void launch_cn(const RowsLaunch& l, const RowsParams& p, dim3 grid, dim3 block, bool first) {
-#define LDPC_CN(R)                                                                                          \
-    if (first) hipLaunchKernelGGL((rows_cn_kernel<FPL, R, true, DC>), grid, block, l.lds_bytes, l.stream, p);   \
-    else       hipLaunchKernelGGL((rows_cn_kernel<FPL, R, false, DC>), grid, block, l.lds_bytes, l.stream, p)
+    constexpr bool kCanFuse = FPL == 1;
+#define LDPC_CN(R)                                                                                                    \
+    if (first) hipLaunchKernelGGL((rows_cn_kernel<FPL, R, true, DC, false>), grid, block, l.lds_bytes, l.stream, p);      \
+    else if (kCanFuse && p.fused)                                                                                     \
+        hipLaunchKernelGGL((rows_cn_kernel<FPL, R, false, DC, kCanFuse>), grid, block, l.lds_bytes, l.stream, p);         \
+    else hipLaunchKernelGGL((rows_cn_kernel<FPL, R, false, DC, false>), grid, block, l.lds_bytes, l.stream, p)
     switch (l.rule) {
         case kCnMinSum: LDPC_CN(kCnMinSum); break;
         case kCnSumProduct: LDPC_CN(kCnSumProduct); break;
@@ -34,8 +37,12 @@ hipError_t run(const RowsLaunch& l, RowsParams p) {
         p.iter = it;
         const bool last = it + 1 == p.b.max_iters;
         launch_cn<FPL, DC>(l, p, grid, block, it == 0);
-        hipLaunchKernelGGL((rows_vn_kernel<FPL, DV>), grid, block, l.lds_bytes, l.stream, p, (p.early || !last) ? 1 : 0);
-        if (last) {  // with early termination the launches above carry the syndrome of the iteration before
+        const int write_beta = (p.early || !last) ? 1 : 0;
+        if (FPL == 1 && p.fused && it > 0)
+            hipLaunchKernelGGL((rows_vn_kernel<FPL, DV, FPL == 1>), grid, block, l.lds_bytes, l.stream, p, write_beta);
+        else
+            hipLaunchKernelGGL((rows_vn_kernel<FPL, DV, false>), grid, block, l.lds_bytes, l.stream, p, write_beta);
+        if (last || (p.early && !p.fused)) {  // fused: the launches above carry the syndrome of the iteration before
             hipLaunchKernelGGL((rows_synd_kernel<FPL>), grid, block, 0, l.stream, p);
             hipLaunchKernelGGL(rows_finish_kernel, sgrid, dim3(256), 0, l.stream, p, slots, last ? 1 : 0);
         }

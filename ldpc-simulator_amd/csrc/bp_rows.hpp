@@ -30,6 +30,7 @@ struct RowsParams {
     int vars_per_chunk;  // variables per wave in a VN launch, a multiple of 32
     int iter;            // iteration this launch belongs to (0-based)
     int early;           // per-frame early termination
+    int fused;           // early termination without launches of its own (see above)
     int32_t* st_done;    // [tiles*T] 0 = still iterating (early mode)
     int32_t* st_acc;     // [2][slots] syndrome weight accumulators, by parity of the iteration they belong to
     int slots;           // tiles * T
@@ -46,7 +47,9 @@ __device__ __forceinline__ bool rows_lane_active(const RowsParams& p, int tile, 
     return true;
 }
 
-// number of unsatisfied checks among rows i0 .. i1-1 of the packed decisions (sumSyndro, LogDecoder.java:108-116)
+// number of unsatisfied checks among rows i0 .. i1-1 of the packed decisions (sumSyndro, LogDecoder.java:108-116),
+// for the check-node launch that carries the syndrome of the previous iteration: a small batch waits on every
+// round trip, so eight loads go out at a time
 template <int FPL>
 __device__ __forceinline__ void rows_syndrome(const BpParams& b, const uint32_t* bits, int i0, int i1, int (&w)[FPL]) {
 #pragma unroll
@@ -94,8 +97,9 @@ __device__ __forceinline__ void rows_syndrome(const BpParams& b, const uint32_t*
 // short waves and nothing else hides the memory latency, waits once per group instead of once per row:
 // every group of a regular code (DC / DV > 0 = the degree of every check / variable), runs of equal
 // degree otherwise.  Same per-row arithmetic, same bits.
-template <int FPL, int RULE, bool FIRST, int DC>
+template <int FPL, int RULE, bool FIRST, int DC, bool FUSED>
 __global__ void __launch_bounds__(256, 4) rows_cn_kernel(RowsParams p) {
+    static_assert(!FUSED || (FPL == 1 && !FIRST), "the syndrome of the previous iteration, one frame per lane");
     extern __shared__ float lds_all[];
     float* lds = lds_all + (long long)(threadIdx.x >> 6) * 2 * p.b.lds_maxd * 64;
     const int lane = threadIdx.x & 63;
@@ -107,12 +111,10 @@ __global__ void __launch_bounds__(256, 4) rows_cn_kernel(RowsParams p) {
     float* msg = p.b.ws_msg + (long long)tile * p.b.msg_tile + lane * FPL;
     const float* lam = p.b.ws_lam + (long long)tile * p.b.lam_tile + lane * FPL;
     if (rows_lane_active<FPL>(p, tile, lane)) {
-        if constexpr (FPL == 1 && !FIRST) {
-            if (p.early) {  // weight of the previous iteration's syndrome over this wave's rows
-                int w[1];
-                rows_syndrome<1>(p.b, p.b.ws_bits + (long long)tile * p.b.bits_tile + lane, i0, i1, w);
-                if (w[0]) atomicAdd(&p.st_acc[(long long)((p.iter - 1) & 1) * p.slots + (long long)tile * kWave + lane], w[0]);
-            }
+        if constexpr (FUSED) {  // weight of the previous iteration's syndrome over this wave's rows
+            int w[1];
+            rows_syndrome<1>(p.b, p.b.ws_bits + (long long)tile * p.b.bits_tile + lane, i0, i1, w);
+            if (w[0]) atomicAdd(&p.st_acc[(long long)((p.iter - 1) & 1) * p.slots + (long long)tile * kWave + lane], w[0]);
         }
         if constexpr (DC > 0) {
             constexpr int G = rows_group<FPL, DC>();
@@ -131,8 +133,9 @@ __global__ void __launch_bounds__(256, 4) rows_cn_kernel(RowsParams p) {
     }
 }
 
-template <int FPL, int DV>
+template <int FPL, int DV, bool FUSED>
 __global__ void __launch_bounds__(256, 4) rows_vn_kernel(RowsParams p, int write_beta) {
+    static_assert(!FUSED || FPL == 1, "early termination runs with one frame per lane");
     extern __shared__ float lds_all[];
     float* lds = lds_all + (long long)(threadIdx.x >> 6) * 2 * p.b.lds_maxd * 64;
     const int lane = threadIdx.x & 63;
@@ -145,8 +148,8 @@ __global__ void __launch_bounds__(256, 4) rows_vn_kernel(RowsParams p, int write
     const float* lam = p.b.ws_lam + (long long)tile * p.b.lam_tile + lane * FPL;
     uint32_t* bits = p.b.ws_bits + (long long)tile * p.b.bits_tile + lane * FPL;
     bool active = rows_lane_active<FPL>(p, tile, lane);
-    if constexpr (FPL == 1) {
-        if (p.early && p.iter > 0) {
+    if constexpr (FUSED) {
+        {
             // the check-node launch of this iteration has left the weight of the previous iteration's syndrome
             const long long slot = (long long)tile * kWave + lane;
             const int w = p.st_acc[(long long)((p.iter - 1) & 1) * p.slots + slot];
@@ -194,7 +197,37 @@ __global__ void __launch_bounds__(256, 4) rows_synd_kernel(RowsParams p) {
     const uint32_t* bits = p.b.ws_bits + (long long)tile * p.b.bits_tile + lane * FPL;
     if (!rows_lane_active<FPL>(p, tile, lane)) return;
     int w[FPL];
-    rows_syndrome<FPL>(p.b, bits, i0, i1, w);
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) w[f] = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int e0 = p.b.row_ptr[i], e1 = p.b.row_ptr[i + 1];
+        uint32_t par[FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) par[f] = 0u;
+        int e = e0;
+        for (; e + 4 <= e1; e += 4) {  // four loads in flight: the row is a chain of cache hits otherwise
+            int j[4];
+            uint32_t v[4][FPL];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                j[u] = p.b.edge_col[e + u];
+                ldw<FPL>(bits + (long long)(j[u] >> 5) * p.b.bits_row, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int f = 0; f < FPL; ++f) par[f] ^= v[u][f] >> (j[u] & 31);
+        }
+        for (; e < e1; ++e) {
+            const int j = p.b.edge_col[e];
+            uint32_t v[FPL];
+            ldw<FPL>(bits + (long long)(j >> 5) * p.b.bits_row, v);
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) par[f] ^= v[f] >> (j & 31);
+        }
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) w[f] += (int)(par[f] & 1u);
+    }
     int32_t* acc = p.st_acc + (long long)(p.iter & 1) * p.slots + (long long)tile * (kWave * FPL) + lane * FPL;
 #pragma unroll
     for (int f = 0; f < FPL; ++f)
@@ -207,6 +240,7 @@ __global__ void __launch_bounds__(256) rows_finish_kernel(RowsParams p, int slot
     if (s >= slots) return;
     if (p.early && p.st_done[s]) return;
     const int w = p.st_acc[(long long)(p.iter & 1) * p.slots + s];
+    p.st_acc[(long long)(p.iter & 1) * p.slots + s] = 0;
     p.st_synd[s] = w;
     if (p.early && w == 0) {
         p.st_done[s] = 1;

@@ -121,8 +121,9 @@ def test_refused_cooperative_launch_is_observable_and_not_final(pkg):
 
 def test_row_chunking_of_small_batches_does_not_change_a_bit(pkg, oracle):
     """A small batch of a code the specialised kernels do not take is cut into short waves, down to 8 variables
-    each, which store their share of a packed decision word as bytes: every cut returns the words of the
-    double oracle, on a length that is no multiple of 8 as well."""
+    each, which store their share of a packed decision word as bytes, and early termination forms its syndrome
+    either in launches of its own or inside the next check-node launch: every combination returns the words of
+    the double oracle, on a length that is no multiple of 8 as well."""
     rng = np.random.default_rng(11)
     _, bg = pkg.codes.nr_bg1_shaped(z=8, seed=3)
     m2, n2 = 150, 301
@@ -138,10 +139,11 @@ def test_row_chunking_of_small_batches_does_not_change_a_bit(pkg, oracle):
         llr = oracle.gen_awgn_llr(m, n, 2.5, seed=9, first_frame=0, frames=F)
         for early, L in ((True, 30), (False, 5)):
             want = g.decode_llr_batch(llr, L, early)
-            for waves in (0, 256, 1024, 4096, 1 << 20):
+            for waves, fused in ((0, -1), (256, 0), (256, 1), (1024, -1), (4096, 0), (4096, 1), (1 << 20, -1)):
                 dec.set_option("rows_waves", waves)
+                dec.set_option("rows_fused", fused)   # the syndrome in launches of its own / inside the next check-node launch
                 got = dec.decode_batch(llr, L, early)
                 assert dec.last_decode_kernel() == "rows_cn_kernel"
                 for x, y in zip(got, want):
-                    assert (x == y).all(), (n, early, waves)
+                    assert (x == y).all(), (n, early, waves, fused)
         dec.close()
