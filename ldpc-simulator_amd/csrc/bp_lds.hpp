@@ -76,13 +76,21 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
     // kept opaque so that they stay in registers instead of being re-formed as base + offset per use
     const uint32_t lds_base = lds_address(msgb);
     uint32_t off[kLdsVpt][DV];
+    {
+        // all table reads first, one wait for the lot (made opaque one by one, each read was waited for in turn)
+        int raw[kLdsVpt][DV];
 #pragma unroll
-    for (int v = 0; v < kLdsVpt; ++v)
+        for (int v = 0; v < kLdsVpt; ++v)
 #pragma unroll
-        for (int k = 0; k < DV; ++k) {
-            off[v][k] = lds_address(msgb + p.vn_off[(long long)(t + v * nt) * DV + k]);
-            asm volatile("" : "+v"(off[v][k]));
-        }
+            for (int k = 0; k < DV; ++k) raw[v][k] = p.vn_off[(long long)(t + v * nt) * DV + k];
+#pragma unroll
+        for (int v = 0; v < kLdsVpt; ++v)
+#pragma unroll
+            for (int k = 0; k < DV; ++k) {
+                off[v][k] = lds_address(msgb + raw[v][k]);
+                asm volatile("" : "+v"(off[v][k]));
+            }
+    }
     // With early termination a workgroup decodes frames blockIdx.x, blockIdx.x + gridDim.x, ... in turn:
     // the addresses above are formed once for all of them, which counts when a frame takes a handful of
     // iterations.  At fixed iterations it takes one frame (the launch gives it no second one), and the
