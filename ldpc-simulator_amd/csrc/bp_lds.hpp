@@ -26,6 +26,7 @@ constexpr int kLdsVpt = 8;  // variables per thread; threads per frame = n / 8, 
 struct LdsParams {
     int m, n, nw;
     long long E;
+    int msg_words;         // floats of LDS the messages take: (m / 2) * lds_pair_stride(DC)
     // Tables built once per code on the host (ldpc_amd.hip, build_resident_tables):
     const int* perm;       // [n]  variable handled at VN position p (thread p % nt, step p / nt)
     const int* pos_of_var; // [n]  inverse of perm
@@ -45,10 +46,16 @@ struct LdsParams {
 // LDS slot of CSR edge e = (check i, position k): the rows of the two checks a thread processes
 // together (i = t + c*nt for c = 2q, 2q+1) are interleaved element by element, so that
 // (check 2q position k, check 2q+1 position k) is one aligned 8-byte pair = one packed register.
+// Floats from one row pair to the next.  The lanes of a wave read their pairs with 16-byte accesses, which the
+// LDS serves in groups of 16 lanes (reads, 64 banks) or 8 lanes (writes, 32 banks): the group is conflict-free
+// when (stride / 4) is odd.  2 * 6 = 12 is; 2 * 8 = 16 puts every fourth lane on the same banks (4-way: the (8,2)
+// kernel ran with its LDS 98 % busy, two thirds of that conflicts), so its rows are 4 floats apart.
+__host__ __device__ constexpr int lds_pair_stride(int dc) { return 2 * dc + ((dc / 2) % 2 == 0 ? 4 : 0); }
+
 __host__ __device__ inline int lds_slot(int e, int dc, int nt) {
     const int i = e / dc, k = e - i * dc;
     const int c = i / nt, t = i - c * nt;
-    return 2 * dc * (t + (c >> 1) * nt) + 2 * k + (c & 1);
+    return lds_pair_stride(dc) * (t + (c >> 1) * nt) + 2 * k + (c & 1);
 }
 
 // LDS accesses by 32-bit LDS address
@@ -66,8 +73,8 @@ template <int DC, int DV, int RULE, bool EARLY, int CPT, int WPE>
 __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
     static_assert(CPT % 2 == 0 && kLdsVpt % 2 == 0, "checks and variables are processed in pairs");
     extern __shared__ __align__(16) float smem[];
-    float* msg = smem;                                        // [E]
-    uint32_t* bits = reinterpret_cast<uint32_t*>(smem + p.E); // [nw], by VN position
+    float* msg = smem;                                        // [msg_words]
+    uint32_t* bits = reinterpret_cast<uint32_t*>(smem + p.msg_words); // [nw], by VN position
     int* red = reinterpret_cast<int*>(bits + p.nw);           // syndrome accumulator
     const int t = threadIdx.x, nt = blockDim.x;
     char* msgb = reinterpret_cast<char*>(msg);
@@ -168,7 +175,7 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
                     uint32_t o = off[v][k];
                     asm volatile("" : "+v"(o));  // formed here, when needed: 24 more loop invariants do not fit
                     const uint32_t slot = (o - lds_base) >> 2;
-                    const uint32_t b = 2u * (slot / (2u * DC)) + (slot & 1u);
+                    const uint32_t b = 2u * (slot / (uint32_t)lds_pair_stride(DC)) + (slot & 1u);
                     atomicXor(&par[b >> 5], 1u << (b & 31u));
                 }
             }
@@ -181,7 +188,7 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
         // check nodes: beta -> alpha in place, two checks per step in the halves of packed registers
 #pragma unroll
         for (int q = 0; q < CPT / 2; ++q) {
-            v2f* row = reinterpret_cast<v2f*>(msg + 2 * DC * (t + q * nt));
+            v2f* row = reinterpret_cast<v2f*>(msg + lds_pair_stride(DC) * (t + q * nt));
             v2f x[DC];
 #pragma unroll
             for (int k = 0; k < DC; ++k) x[k] = row[k];

@@ -415,14 +415,15 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         // exact tiling: 8 variables and 8 m / n checks per thread, whole wavefronts
         const int nt = n / kLdsVpt;
         // messages | packed decisions | accumulator | one syndrome bit per check
-        const size_t lds_bytes = ((size_t)c->E + (size_t)c->nw + 4 + (size_t)(c->m + 31) / 32) * sizeof(float);
+        const size_t msg_words = (size_t)(c->m / 2) * (size_t)lds_pair_stride(std::max(c->reg_dc, 2));
+        const size_t lds_bytes = (msg_words + (size_t)c->nw + 4 + (size_t)(c->m + 31) / 32) * sizeof(float);
         bool use = shape && n % (kLdsVpt * 64) == 0 && nt <= 512 && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll &&
                    c->m <= 2048;  // the convergence test reads the syndrome words with one wavefront
         if (c->opt.engine != LDPC_AMD_ENGINE_AUTO) use = false;
         if (use) {
             if (int rc = build_resident_tables(c, nt)) return rc;
             LdsParams q{};
-            q.m = c->m; q.n = n; q.nw = c->nw; q.E = c->E;
+            q.m = c->m; q.n = n; q.nw = c->nw; q.E = c->E; q.msg_words = (int)msg_words;
             q.perm = c->d_res; q.pos_of_var = q.perm + n; q.vn_off = q.pos_of_var + n;
             q.llr = src.kind == Src::Float ? src.llr : nullptr;
             q.r = src.kind == Src::Bsc ? src.r : nullptr;
