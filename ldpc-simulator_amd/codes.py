@@ -69,6 +69,41 @@ def regular_ldpc(n, dv, dc, seed, max_repair_rounds=200):
     return _sorted_coo(m, n, rows, cols)
 
 
+def dvbs2_like(n=64800, seed=1, heavy_fraction=0.4, heavy_degree=8, light_degree=3, max_repair_rounds=200):
+    """Irregular repeat-accumulate code of rate 1/2 with the degree profile of the long DVB-S2 rate-1/2 code
+    (ETSI EN 302 307: n = 64800, 12960 information columns of degree 8, 19440 of degree 3, 32400 parity columns
+    in a staircase of degree 2, the last of degree 1; E = 226,799).  The connections of the information part
+    are a seeded socket permutation with repeated-edge repair, not the standard's address tables (which the
+    reference does not contain either): the shape, not the code.  Check i holds parity columns k + i and
+    k + i - 1; every check has the same number of information edges."""
+    k = n // 2
+    m = n - k
+    heavy = int(round(k * heavy_fraction))
+    deg = np.where(np.arange(k) < heavy, heavy_degree, light_degree)
+    total = int(deg.sum())
+    if total % m:
+        raise ValueError("information edges must divide evenly over the checks")
+    rng = np.random.default_rng(seed)
+    cols = np.repeat(np.arange(k), deg)
+    rows = np.repeat(np.arange(m), total // m)[rng.permutation(total)]
+    for _ in range(max_repair_rounds):
+        key = rows.astype(np.int64) * n + cols
+        order = np.argsort(key, kind="stable")
+        dup = np.zeros(key.size, bool)
+        dup[order[1:]] = key[order[1:]] == key[order[:-1]]
+        bad = np.nonzero(dup)[0]
+        if bad.size == 0:
+            break
+        other = rng.integers(0, key.size, bad.size)
+        for a, b in zip(bad, other):
+            rows[a], rows[b] = rows[b], rows[a]
+    else:
+        raise RuntimeError("could not remove repeated edges")
+    stair_r = np.concatenate([np.arange(m), np.arange(1, m)])
+    stair_c = np.concatenate([k + np.arange(m), k + np.arange(m - 1)])
+    return _sorted_coo(m, n, np.concatenate([rows, stair_r]), np.concatenate([cols, stair_c]))
+
+
 def qc_expand(base, z):
     """Expand a base matrix of shifts (-1 = zero block) by circulants of size z:
     H[i*z + k][j*z + (k + s) % z] = 1  (src/LDPC/GenerateMatrix.java:139-150)."""

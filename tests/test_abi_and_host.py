@@ -248,3 +248,20 @@ def test_cpp_host_mirror_runs(tmp_path):
     _build_host_example(tmp_path / "example_decode")
     r = subprocess.run([str(tmp_path / "example_decode")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "decodedCode = 000  iterationNum = 1  syndrome = 0" in r.stdout, r.stdout + r.stderr
+
+
+def test_dvbs2_shaped_builder(pkg):
+    """Degree profile of the long DVB-S2 rate-1/2 code: 12960 columns of degree 8, 19440 of degree 3, a parity
+    staircase of degree 2 whose last column has degree 1; 226,799 edges; every check but the first of degree 7."""
+    import numpy as np
+    m, n, rows, cols = pkg.codes.dvbs2_like(64800, seed=3)
+    assert (m, n, len(rows)) == (32400, 64800, 226799)
+    dc, dv = pkg.codes.degrees(m, n, rows, cols)
+    assert (dv[:12960] == 8).all() and (dv[12960:32400] == 3).all() and (dv[32400:-1] == 2).all() and dv[-1] == 1
+    assert dc[0] == 6 and (dc[1:] == 7).all()
+    key = rows.astype(np.int64) * n + cols
+    assert (np.diff(key) > 0).all()                      # row-major order, no repeated entry
+    # the parity part is the staircase: check i holds columns k + i and k + i - 1
+    k = n - m
+    par = cols >= k
+    assert (np.abs((cols[par] - k) - rows[par]) <= 1).all() and ((cols[par] - k) <= rows[par]).all()

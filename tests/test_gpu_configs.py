@@ -65,6 +65,26 @@ def test_config5_long_code_small_batch_early_exit(pkg, oracle):
         assert (got[1] < 50).all() and (got[2] == 0).all()
 
 
+def test_config5_dvbs2_shaped_code_small_batches(pkg, oracle):
+    """Config 5 on an irregular long code: the degree profile of the DVB-S2 rate-1/2 code (n = 64800, E = 226,799:
+    information columns of degree 8 and 3, a parity staircase of degree 2), 1 to 33 frames with early
+    termination.  One frame goes through the node-parallel kernel, 33 through the finely cut sweeps; all equal
+    to the double oracle."""
+    m, n, rows, cols = pkg.codes.dvbs2_like(64800, seed=1)
+    assert len(rows) == 226799
+    dec = pkg.Decoder(m, n, rows, cols)
+    g = oracle.Graph(m, n, rows, cols)
+    for F, kernel in ((1, "bp_nodes_kernel"), (8, None), (33, "rows_cn_kernel")):
+        llr = oracle.gen_awgn_llr(m, n, 1.5, seed=8, first_frame=0, frames=F)
+        got = dec.decode_batch(llr, 50, True)
+        if kernel:
+            assert dec.last_decode_kernel() == kernel
+        want = g.decode_llr_batch(llr, 50, True)
+        assert (got[0] == want[0]).all()
+        assert (got[1] == want[1]).all() and (got[2] == want[2]).all()
+        assert (got[1] < 50).all() and (got[2] == 0).all()
+
+
 def _ci95(k, nobs):
     """Wilson 95 % interval for k successes in nobs trials."""
     if nobs == 0:

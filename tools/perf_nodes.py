@@ -46,5 +46,8 @@ ok &= run("C4 BG1-shaped Z=384 0.5 dB", bg, 7, 30, True, 0.5)
 for F in (1, 4, 8, 12, 16, 24, 32):
     ok &= run("C5 (3,6) n=64800 1.6 dB", c5, F, 50, True, 1.6)
 ok &= run("C5 (3,6) n=64800 1.0 dB", c5, 3, 20, True, 1.0)
+dvb = L.codes.dvbs2_like(64800, 1)
+for F in (1, 4, 8, 16, 32):
+    ok &= run("C5 DVB-S2-shaped n=64800 1.5 dB", dvb, F, 50, True, 1.5)
 print("ALL IDENTICAL" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
