@@ -66,6 +66,9 @@ __device__ __forceinline__ uint32_t lds_address(const void* generic) {
 __device__ __forceinline__ float lds_load(uint32_t a) { return *(const lds_float*)(uintptr_t)a; }
 __device__ __forceinline__ void lds_store(uint32_t a, float v) { *(lds_float*)(uintptr_t)a = v; }
 
+struct LdsYes { static constexpr bool value = true; };
+struct LdsNo { static constexpr bool value = false; };
+
 // CPT (even) checks and kLdsVpt variables per thread, exactly: m = CPT * blockDim.x, n = kLdsVpt * blockDim.x.
 // WPE = wavefronts per SIMD the register budget is set for: 6 (80 registers, three 8-wave workgroups
 // per CU) or 4 (128 registers, two).
@@ -184,7 +187,11 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
 
     int iters = p.max_iters, synd = 0;
     bool converged = false;
-    for (int it = 0; it < p.max_iters; ++it) {
+    // One iteration up to the barrier that ends its variable-node phase.  DECIDE: also form the decisions; at
+    // fixed iterations only the last iteration's are ever read (LogDecoder.java:98-105 forms them every time,
+    // LogDecoder.java:122 returns the last), so the others skip the posterior sum and the sign tests.
+    auto iteration = [&](auto decide, bool write_beta) -> uint32_t {
+        constexpr bool DECIDE = decltype(decide)::value;
         // check nodes: beta -> alpha in place, two checks per step in the halves of packed registers
 #pragma unroll
         for (int q = 0; q < CPT / 2; ++q) {
@@ -209,7 +216,6 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
         __syncthreads();
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit
         // (all gathers are issued before any scatter: distinct variables never share a slot)
-        const bool write_beta = EARLY || (it + 1 < p.max_iters);
         v2f va[kLdsVpt / 2][DV];
 #pragma unroll
         for (int v = 0; v < kLdsVpt; v += 2)
@@ -228,9 +234,13 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
                 }
             }
             // "(gamma[j] < 0) ? 1 : 0", :104
-            newdec |= (g.x < 0.0f ? 1u : 0u) << v | (g.y < 0.0f ? 1u : 0u) << (v + 1);
+            if constexpr (DECIDE) newdec |= (g.x < 0.0f ? 1u : 0u) << v | (g.y < 0.0f ? 1u : 0u) << (v + 1);
         }
-        if constexpr (EARLY) {
+        return newdec;
+    };
+    if constexpr (EARLY) {
+        for (int it = 0; it < p.max_iters; ++it) {
+            const uint32_t newdec = iteration(LdsYes{}, true);
             const uint32_t changed = newdec ^ mydec;
             mydec = newdec;
             if (changed) toggle_checks(changed);  // rare after the first iterations
@@ -245,10 +255,14 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
                 converged = true;
                 break;
             }
-        } else {
-            mydec = newdec;
+        }
+    } else {
+        for (int it = 0; it + 1 < p.max_iters; ++it) {
+            iteration(LdsNo{}, true);
             __syncthreads();
         }
+        mydec = iteration(LdsYes{}, false);
+        __syncthreads();
     }
     // decisions -> packed words by VN position: position t + v*nt of lane 0 of a wave is a multiple of 64, so its
     // word is (t >> 5) + v * (nt >> 5)
