@@ -125,8 +125,10 @@ __global__ void __launch_bounds__(256) gen_awgn_kernel(int n, float a, float b, 
         const float u2 = (float)xs[2 * h + 1] * 2.3283064365386963e-10f;
         const float rad = sqrtf(-2.0f * logf(u1));
         const float th = 6.283185307179586f * u2;
-        z[2 * h] = rad * cosf(th);
-        z[2 * h + 1] = rad * sinf(th);
+        float sn, cs;
+        sincosf(th, &sn, &cs);   // one argument reduction for both; the same values as sinf and cosf
+        z[2 * h] = rad * cs;
+        z[2 * h + 1] = rad * sn;
     }
     // bit 0 is sent as +1, bit 1 as -1: llr = 2 y / sigma^2 with y = (1 - 2c) + sigma z
     float v[4];
