@@ -169,8 +169,12 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
     int iters = p.max_iters, synd = 0;
     for (int it = 0; it < p.max_iters; ++it) {
         // check nodes: beta -> alpha in place (LogDecoder.java:82-95)
+        // the descriptor of the next step is requested before this step's work: a step is a chain of dependent
+        // reads (descriptor, then slots) and few waves share a SIMD here
+        int4 cd_next = p.cn_desc[t];
         for (int s = 0; s < p.cn_steps; ++s) {
-            const int4 cd = p.cn_desc[t + s * nt];
+            const int4 cd = cd_next;
+            if (s + 1 < p.cn_steps) cd_next = p.cn_desc[t + (s + 1) * nt];
             if (RULE == kCnComplement && cd.y == cd.w && cd.y <= kLdsGenPairDc) {
                 switch (cd.y) {
                     case 0: break;
@@ -187,9 +191,14 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit (:67-79, :98-105)
         const bool write_beta = EARLY || (it + 1 < p.max_iters);
         uint32_t newdec = 0u;
+        int4 va_next = p.vn_desc[2 * t], vb_next = p.vn_desc[2 * t + 1];
         for (int s = 0; s < p.vn_steps; ++s) {
-            const int item = t + s * nt;
-            const int4 va = p.vn_desc[2 * item], vb = p.vn_desc[2 * item + 1];
+            const int4 va = va_next, vb = vb_next;
+            if (s + 1 < p.vn_steps) {
+                const int item_next = t + (s + 1) * nt;
+                va_next = p.vn_desc[2 * item_next];
+                vb_next = p.vn_desc[2 * item_next + 1];
+            }
             v2f g = v2f{0.0f, 0.0f};
             if (va.x >= 0 && vb.x >= 0 && va.z == vb.z && va.z <= kLdsGenPairDv) {
                 switch (va.z) {

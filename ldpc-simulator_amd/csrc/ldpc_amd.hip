@@ -31,7 +31,7 @@ struct Options {
     int sim_overlap = 1;
     int verbose = 0;
     int lds_wpe = 0, lds_fpw = 0, generic_lds_kb = 0, nodes_blocks = 0, fpl = 0, layout = 0, rows_waves = 0, wps = 0,
-        nopipe = 0, rows_fused = -1;
+        nopipe = 0, rows_fused = -1, generic_threads = 0;
     int test_nodes_oversize = 0;
 };
 
@@ -460,8 +460,14 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     // Generic frame-resident engine: any code whose messages and LLRs fit into a CU's LDS and whose
     // degrees the register code covers.
     if (!noalloc) {
-        // about 8 variables per thread, whole wavefronts, at most 512 threads
-        const int nt = std::min(512, std::max(64, ((std::max(n, c->m) + 7) / 8 + 63) / 64 * 64));
+        // at least 8 variables per thread, in 1, 2, 3, 4 or 8 whole wavefronts: workgroups of 5 to 7 wavefronts
+        // spread unevenly over the 4 SIMDs and measured up to 1.5x slower (NR-BG1-shaped Z = 32, n = 2176, 65,536
+        // frames x 50 iterations: 320 threads 78 ms, 384 threads 71 ms, 512 threads 53 ms, 256 threads 48 ms);
+        // fewer threads than that mean more steps per phase, each a chain of dependent table reads
+        int nt = 512;
+        for (int cand : {64, 128, 192, 256, 512})
+            if (cand >= (std::max(n, c->m) + 7) / 8) { nt = cand; break; }
+        if (c->opt.generic_threads) nt = c->opt.generic_threads;  // measurements
         bool use = c->m > 0 && c->max_dc <= kLdsGenMaxDc && c->max_dv <= kLdsGenMaxDv && frames <= 0x7fffffffll &&
                    (size_t)c->E * sizeof(float) <= 160 * 1024;
         if (c->opt.engine == LDPC_AMD_ENGINE_STREAM) use = false;
@@ -477,6 +483,9 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             size_t lds_limit = 160 * 1024;
             if (c->opt.generic_lds_kb) lds_limit = c->opt.generic_lds_kb < 0 ? 0 : (size_t)c->opt.generic_lds_kb * 1024;  // measurements
             use = lds_bytes <= lds_limit && c->gen_vn_steps <= 16;  // 2 decision bits per step in one register
+            if (c->opt.verbose)
+                fprintf(stderr, "ldpc_amd: generic resident engine: %d threads per frame, %d + %d steps, %zu bytes of LDS\n", nt,
+                        c->gen_cn_steps, c->gen_vn_steps, lds_bytes);
         }
         if (use) {
             LdsGenParams q{};
@@ -1043,6 +1052,7 @@ int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
         case LDPC_AMD_OPT_TUNE_WPS: if (!(value == 0 || value == 2 || value == 4)) break; o.wps = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_NOPIPE: if (!range(0, 1)) break; o.nopipe = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_ROWS_FUSED: if (!range(-1, 1)) break; o.rows_fused = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: if (!(value == 0 || (value >= 64 && value <= 512 && value % 64 == 0))) break; o.generic_threads = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: if (!range(0, 1)) break; o.test_nodes_oversize = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_NODES_REFUSALS:
         case LDPC_AMD_OPT_NODES_LAST_HIP_ERROR:
@@ -1072,6 +1082,7 @@ int ldpc_amd_get_option(const ldpc_amd_ctx* c, int32_t key, int64_t* value) {
         case LDPC_AMD_OPT_TUNE_WPS: *value = o.wps; break;
         case LDPC_AMD_OPT_TUNE_NOPIPE: *value = o.nopipe; break;
         case LDPC_AMD_OPT_TUNE_ROWS_FUSED: *value = o.rows_fused; break;
+        case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: *value = o.generic_threads; break;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: *value = o.test_nodes_oversize; break;
         case LDPC_AMD_OPT_NODES_REFUSALS: *value = c->nodes_refusals; break;
         case LDPC_AMD_OPT_NODES_LAST_HIP_ERROR: *value = c->nodes_last_error; break;
