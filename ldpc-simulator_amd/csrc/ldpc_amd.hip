@@ -71,6 +71,7 @@ struct ldpc_amd_ctx {
     int res_nt = 0;
     int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E]
     double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
+    int res_clean_groups = 0;   // half wavefronts whose gathers are all conflict-free
     // tables of the generic frame-resident engine: cn_desc | vn_desc | pos_of_var[n] | edge_pos[E] | edge_slot[E] | col_slot[E] | col_check[E]
     int gen_nt = 0, gen_cn_steps = 0, gen_vn_steps = 0, gen_slots = 0;
     // node-parallel cooperative engine: blocks that can be resident at once (0: not asked yet, -1: not available)
@@ -191,24 +192,166 @@ int ensure_stage(ldpc_amd_ctx* c, int slot, size_t bytes) {
     return LDPC_AMD_OK;
 }
 
-// Tables of the frame-resident engine.  Variables are assigned to VN positions (thread p % nt, step
-// p / nt) so that the 32 lanes of a half wavefront, which the LDS serves together for 4-byte
-// accesses, find their k-th edge slots in 32 different banks (bank = dword address mod 32): a greedy
-// fill, group by group.  The assignment only changes which lane owns which variable; every
-// variable still sums its own edges in ascending check order.
+// Deterministic generator for the placement searches below: the tables must not depend on the C library.
+struct PlaceRng {
+    uint64_t s;
+    uint32_t next() {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        return (uint32_t)(s >> 33);  // 31 bits
+    }
+    int below(int n) { return (int)(((uint64_t)next() * (uint64_t)n) >> 31); }
+};
+
+// Tables of the frame-resident engine.  In the variable-node phase the 32 lanes of a half wavefront, which
+// the LDS serves together for 4-byte accesses, read (and later write) the k-th edge slots of their variables:
+// one LDS cycle if the 32 slots lie in 32 different banks (bank = dword address mod 32), N cycles if some bank
+// is hit N times.  Two things are free and are chosen here so that most half wavefronts get their 32 banks:
+//   1. which row of the message array a check owns (any one-to-one placement serves: a row is processed by
+//      whatever thread it belongs to, and the syndrome bits are numbered by rows).  A local search over
+//      swaps of two checks' rows flattens, for every k, the histogram of the banks of all k-th edge slots -
+//      without that no group of 32 variables can cover the 32 banks (natural placement of the (3,6) n = 4096
+//      code: 70 to 184 slots per bank where 128 are needed);
+//   2. which lane owns which variable (position p = thread p % nt, step p / nt): groups of 32 variables that
+//      are transversals of the banks in every k at once are built one after the other, always serving the
+//      scarcest (k, bank) among the variables still compatible, with random restarts; what is left when no
+//      such group is found any more is filled greedily, level by level.
+// (3,6) n = 4096: 103 of 128 groups conflict-free, mean worst multiplicity 2.10 -> 1.21.  The assignment only
+// changes which lane owns which variable and where a check's row lies; every variable still sums its own
+// edges in ascending check order and every check its own in ascending variable order.
 int build_resident_tables(ldpc_amd_ctx* c, int nt) {
     if (c->d_res && c->res_nt == nt) return LDPC_AMD_OK;
-    const int n = c->n, dc = c->reg_dc, dv = c->reg_dv;
+    const int n = c->n, m = c->m, dc = c->reg_dc, dv = c->reg_dv;
     const long long E = c->E;
+    const int target = n / 32;
+    // coordinate of an edge: its rank among the edges of its variable
+    std::vector<unsigned char> coord((size_t)E);
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < dv; ++k) coord[(size_t)c->h_col_edge[(size_t)j * dv + k]] = (unsigned char)k;
+    // 1. rows of the checks
+    std::vector<int> where((size_t)m);  // check i owns the row that check index where[i] has in lds_slot()
+    for (int i = 0; i < m; ++i) where[(size_t)i] = i;
+    auto bank_of = [&](int i, int kk) { return lds_slot(where[(size_t)i] * dc + kk, dc, nt) & 31; };
+    std::vector<int> hist((size_t)dv * 32, 0);
+    for (int i = 0; i < m; ++i)
+        for (int kk = 0; kk < dc; ++kk) ++hist[(size_t)coord[(size_t)i * dc + kk] * 32 + bank_of(i, kk)];
+    {
+        PlaceRng rng{0x9E3779B97F4A7C15ull};
+        auto deviation = [&]() {
+            long long d = 0;
+            for (int v : hist) d += (long long)(v - target) * (v - target);
+            return d;
+        };
+        long long dev = deviation();
+        struct Change { int bin, by; };
+        std::vector<Change> done;
+        for (long long it = 0; it < 64ll * m && dev > 0; ++it) {
+            const int a = rng.below(m), b2 = rng.below(m);
+            if (a == b2) continue;
+            done.clear();
+            long long delta = 0;
+            auto apply = [&](int bin, int by) {
+                const int h = hist[(size_t)bin] - target;
+                delta += by > 0 ? 2 * h + 1 : -2 * h + 1;
+                hist[(size_t)bin] += by;
+                done.push_back(Change{bin, by});
+            };
+            for (int kk = 0; kk < dc; ++kk) {
+                apply(coord[(size_t)a * dc + kk] * 32 + bank_of(a, kk), -1);
+                apply(coord[(size_t)b2 * dc + kk] * 32 + bank_of(b2, kk), -1);
+            }
+            std::swap(where[(size_t)a], where[(size_t)b2]);
+            for (int kk = 0; kk < dc; ++kk) {
+                apply(coord[(size_t)a * dc + kk] * 32 + bank_of(a, kk), +1);
+                apply(coord[(size_t)b2 * dc + kk] * 32 + bank_of(b2, kk), +1);
+            }
+            if (delta < 0) {
+                dev += delta;
+            } else {  // no gain: undo
+                std::swap(where[(size_t)a], where[(size_t)b2]);
+                for (const Change& ch : done) hist[(size_t)ch.bin] -= ch.by;
+            }
+        }
+    }
     std::vector<int> slot((size_t)E);
-    for (long long e = 0; e < E; ++e) slot[(size_t)e] = lds_slot((int)e, dc, nt);
+    for (long long e = 0; e < E; ++e) {
+        const int i = (int)(e / dc), kk = (int)(e - (long long)i * dc);
+        slot[(size_t)e] = lds_slot(where[(size_t)i] * dc + kk, dc, nt);
+    }
+    // 2. lanes of the variables
+    std::vector<unsigned char> bank((size_t)n * dv);
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < dv; ++k) bank[(size_t)j * dv + k] = (unsigned char)(slot[(size_t)c->h_col_edge[(size_t)j * dv + k]] & 31);
     std::vector<int> perm((size_t)n), pos((size_t)n);
     std::vector<char> taken((size_t)n, 0);
-    std::vector<int> order((size_t)n);
-    for (int j = 0; j < n; ++j) order[(size_t)j] = j;
+    int next_group = 0;
+    const int groups = n / 32;
+    {
+        PlaceRng rng{0xD1B54A32D192ED03ull};
+        std::vector<int> pool((size_t)n), cand, keep;
+        for (int j = 0; j < n; ++j) pool[(size_t)j] = j;
+        int members[32];
+        bool used[8][32];
+        int cnt[8][32];
+        int failures = 0;
+        while (next_group < groups && (int)pool.size() >= 32 && failures < 3) {
+            bool found = false;
+            for (int attempt = 0; attempt < 40 && !found; ++attempt) {
+                memset(used, 0, sizeof(used));
+                cand = pool;
+                int got = 0;
+                bool ok = true;
+                for (int s2 = 0; s2 < 32 && ok; ++s2) {
+                    // the variables still compatible with the banks taken so far, and how many serve each bank
+                    keep.clear();
+                    memset(cnt, 0, sizeof(cnt));
+                    for (int j : cand) {
+                        bool fits = true;
+                        for (int k = 0; k < dv && fits; ++k) fits = !used[k][bank[(size_t)j * dv + k]];
+                        if (!fits) continue;
+                        keep.push_back(j);
+                        for (int k = 0; k < dv; ++k) ++cnt[k][bank[(size_t)j * dv + k]];
+                    }
+                    cand.swap(keep);
+                    // the scarcest (k, bank) still to be served; none may have run dry
+                    int best_k = -1, best_b = -1, best_cnt = 1 << 30;
+                    for (int k = 0; k < dv && ok; ++k)
+                        for (int bb = 0; bb < 32; ++bb) {
+                            if (used[k][bb]) continue;
+                            if (cnt[k][bb] == 0) { ok = false; break; }
+                            // ties broken at random, so that attempts differ
+                            const int key = cnt[k][bb] * 4 + (int)(rng.next() & 3);
+                            if (key < best_cnt) { best_cnt = key; best_k = k; best_b = bb; }
+                        }
+                    if (!ok) break;
+                    int pick = rng.below(cnt[best_k][best_b]), chosen = -1;
+                    for (int j : cand)
+                        if (bank[(size_t)j * dv + best_k] == best_b && pick-- == 0) { chosen = j; break; }
+                    members[got++] = chosen;
+                    for (int k = 0; k < dv; ++k) used[k][bank[(size_t)chosen * dv + k]] = true;
+                }
+                found = ok && got == 32;
+            }
+            if (!found) {
+                ++failures;
+                continue;
+            }
+            failures = 0;
+            const int v = next_group / (nt / 32), h = next_group % (nt / 32);
+            for (int l = 0; l < 32; ++l) {
+                const int p = (32 * h + l) + v * nt;
+                perm[(size_t)p] = members[l];
+                pos[(size_t)members[l]] = p;
+                taken[(size_t)members[l]] = 1;
+            }
+            keep.clear();
+            for (int j : pool)
+                if (!taken[(size_t)j]) keep.push_back(j);
+            pool.swap(keep);
+            ++next_group;
+        }
+    }
     int first_free = 0;
-    long long mult_sum = 0, mult_cnt = 0;
-    for (int g = 0; g < n / 32; ++g) {
+    for (int g = next_group; g < groups; ++g) {
         // group g = positions with step v = g / (nt/32) and lanes [32 h, 32 h + 32), h = g % (nt/32)
         const int v = g / (nt / 32), h = g % (nt / 32);
         // pass L admits a variable only if none of its banks would be used more than L times
@@ -221,10 +364,9 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt) {
             for (int j = first_free; j < n && got < 32; ++j) {
                 if (taken[(size_t)j]) continue;
                 bool ok = true;
-                for (int k = 0; k < dv && ok; ++k)
-                    ok = cnt[k][slot[(size_t)c->h_col_edge[(size_t)j * dv + k]] & 31] < level;
+                for (int k = 0; k < dv && ok; ++k) ok = cnt[k][bank[(size_t)j * dv + k]] < level;
                 if (!ok) continue;
-                for (int k = 0; k < dv; ++k) ++cnt[k][slot[(size_t)c->h_col_edge[(size_t)j * dv + k]] & 31];
+                for (int k = 0; k < dv; ++k) ++cnt[k][bank[(size_t)j * dv + k]];
                 taken[(size_t)j] = 1;
                 members[got++] = j;
             }
@@ -234,13 +376,23 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt) {
             perm[(size_t)p] = members[l];
             pos[(size_t)members[l]] = p;
         }
-        for (int k = 0; k < dv; ++k) {  // statistics: worst bank multiplicity of this group's k-th gather
-            int worst = 0;
-            for (int b = 0; b < 32; ++b) worst = std::max(worst, (int)cnt[k][b]);
+    }
+    // statistics: worst bank multiplicity of every group's k-th gather
+    long long mult_sum = 0, mult_cnt = 0;
+    int clean = 0;
+    for (int g = 0; g < groups; ++g) {
+        const int v = g / (nt / 32), h = g % (nt / 32);
+        int group_worst = 0;
+        for (int k = 0; k < dv; ++k) {
+            int cnt[32] = {0}, worst = 0;
+            for (int l = 0; l < 32; ++l) worst = std::max(worst, ++cnt[bank[(size_t)perm[(size_t)((32 * h + l) + v * nt)] * dv + k]]);
             mult_sum += worst;
             ++mult_cnt;
+            group_worst = std::max(group_worst, worst);
         }
+        clean += group_worst == 1;
     }
+    c->res_clean_groups = clean;
     c->res_conflict = mult_cnt ? (double)mult_sum / (double)mult_cnt : 1.0;
     // layout: perm[n] (variable at each position) | pos[n] (position of each variable) | vn_off[E] (byte
     // offsets of the edge slots of the variable at each position)
@@ -261,8 +413,8 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt) {
     LDPC_HIP(c, hipMemcpy(c->d_res, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
     c->res_nt = nt;
     if (c->opt.verbose)
-        fprintf(stderr, "ldpc_amd: resident tables nt=%d, mean worst bank multiplicity of VN gathers %.3f\n", nt,
-                c->res_conflict);
+        fprintf(stderr, "ldpc_amd: resident tables nt=%d, mean worst bank multiplicity of VN gathers %.3f, %d of %d half wavefronts conflict-free\n",
+                nt, c->res_conflict, c->res_clean_groups, n / 32);
     return LDPC_AMD_OK;
 }
 
