@@ -202,6 +202,27 @@ __device__ __forceinline__ float vsign1(float x) {
     return __uint_as_float((__float_as_uint(x) & 0x80000000u) | 0x3f800000u);
 }
 __device__ __forceinline__ v2f vsign1(v2f x) { return v2f{vsign1(x.x), vsign1(x.y)}; }
+// The sign bits of a value over the lanes of the wavefront, one 64-bit lane mask per element.  Lane masks live
+// in scalar registers: products of signs are s_xor_b64 on the scalar unit, which issues beside the vector
+// instructions, and a sign is applied with one v_cndmask_b32 (negated source), where +-1.0 factors cost a
+// v_bfi_b32 and three multiplications per message.  Inactive lanes read as 0 and are not written.
+struct SignMask1 { unsigned long long m; };
+struct SignMask2 { unsigned long long x, y; };
+__device__ __forceinline__ unsigned long long sign_lanes(float x) {
+    return __builtin_amdgcn_ballot_w64((int32_t)__float_as_uint(x) < 0);  // the sign bit itself: -0 and NaN included
+}
+__device__ __forceinline__ SignMask1 vsignmask(float x) { return SignMask1{sign_lanes(x)}; }
+__device__ __forceinline__ SignMask2 vsignmask(v2f x) { return SignMask2{sign_lanes(x.x), sign_lanes(x.y)}; }
+__device__ __forceinline__ SignMask1 operator^(SignMask1 a, SignMask1 b) { return SignMask1{a.m ^ b.m}; }
+__device__ __forceinline__ SignMask2 operator^(SignMask2 a, SignMask2 b) { return SignMask2{a.x ^ b.x, a.y ^ b.y}; }
+// x with its sign flipped in the lanes of the mask: x * (-1.0) there, x * 1.0 elsewhere
+__device__ __forceinline__ float vflip(float x, SignMask1 s) { return __builtin_amdgcn_inverse_ballot_w64(s.m) ? -x : x; }
+__device__ __forceinline__ v2f vflip(v2f x, SignMask2 s) {
+    return v2f{__builtin_amdgcn_inverse_ballot_w64(s.x) ? -x.x : x.x, __builtin_amdgcn_inverse_ballot_w64(s.y) ? -x.y : x.y};
+}
+template <class V> struct SignMaskOf;
+template <> struct SignMaskOf<float> { typedef SignMask1 type; static __device__ __forceinline__ SignMask1 none() { return SignMask1{0ull}; } };
+template <> struct SignMaskOf<v2f> { typedef SignMask2 type; static __device__ __forceinline__ SignMask2 none() { return SignMask2{0ull, 0ull}; } };
 __device__ __forceinline__ float vabs(float x) { return fabsf(x); }
 __device__ __forceinline__ v2f vabs(v2f x) { return v2f{fabsf(x.x), fabsf(x.y)}; }
 template <class V> __device__ __forceinline__ V vsplat(float x);
@@ -240,28 +261,30 @@ __device__ __forceinline__ V atanh2_complement(V Q) {
 
 // beta[0..D) -> alpha[0..D) in place.  Products ascend over k like those of LogDecoder.java:86-91;
 // leave-one-out is (prefix of k) * (suffix of k).  The sign of alpha_k is the product of the other
-// members' signs, formed as (product of all) * (own): exact for factors of +-1.
+// members' signs, formed as (product of all) * (own) on lane masks of the sign bits.
 template <class V, int D>
 __device__ __forceinline__ void cn_complement(V (&b)[D]) {
 #pragma clang fp contract(off)
     const V one = vsplat<V>(1.0f);
-    V q[D], sg[D], pq[D];
-    V Q = vsplat<V>(0.0f), all = one;
+    typedef typename SignMaskOf<V>::type S;
+    V q[D], pq[D];
+    S sg[D], all = SignMaskOf<V>::none();
+    V Q = vsplat<V>(0.0f);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        sg[k] = vsign1(b[k]);
+        sg[k] = vsignmask(b[k]);
         q[k] = tanh_complement<V>(b[k]);
         pq[k] = Q;
         // the first step is fma(q, 1 - 0, 0) = q exactly (q is never -0; NaN stays NaN): no instruction
         Q = (k == 0) ? q[k] : vfma(q[k], one - Q, Q);
-        all = all * sg[k];
+        all = all ^ sg[k];
     }
     V sQ = vsplat<V>(0.0f);
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
         // for the last member the suffix is empty: fma(0, 1 - pq, pq) = pq exactly (pq lies in [0, 1] or is NaN)
         const V mag = atanh2_complement<V>((k == D - 1) ? pq[k] : vfma(sQ, one - pq[k], pq[k]));
-        b[k] = mag * (all * sg[k]);
+        b[k] = vflip(mag, all ^ sg[k]);
         sQ = (k == D - 1) ? q[k] : vfma(q[k], one - sQ, sQ);
     }
 }

@@ -21,7 +21,8 @@
 
 namespace ldpc {
 
-constexpr int kLdsVpt = 8;  // variables per thread; threads per frame = n / 8, checks per thread = 8 m / n
+constexpr int kLdsVpt = 8;   // variables per thread; threads per frame = n / 8, checks per thread = 8 m / n
+constexpr int kLdsVptWide = 16;  // the second tiling: half as many threads per frame, each with twice the nodes
 
 struct LdsParams {
     int m, n, nw;
@@ -69,12 +70,14 @@ __device__ __forceinline__ void lds_store(uint32_t a, float v) { *(lds_float*)(u
 struct LdsYes { static constexpr bool value = true; };
 struct LdsNo { static constexpr bool value = false; };
 
-// CPT (even) checks and kLdsVpt variables per thread, exactly: m = CPT * blockDim.x, n = kLdsVpt * blockDim.x.
-// WPE = wavefronts per SIMD the register budget is set for: 6 (80 registers, three 8-wave workgroups
-// per CU) or 4 (128 registers, two).
-template <int DC, int DV, int RULE, bool EARLY, int CPT, int WPE>
-__global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
-    static_assert(CPT % 2 == 0 && kLdsVpt % 2 == 0, "checks and variables are processed in pairs");
+// VPT variables and CPT = VPT * DV / DC (even) checks per thread, exactly: n = VPT * blockDim.x, m = CPT * blockDim.x.
+// WPE = wavefronts per SIMD the register budget is set for.  VPT = 8: 6 (80 registers, three 8-wave workgroups
+// per CU) or 4 (128 registers, two).  VPT = 16: 3 (168 registers, three 4-wave workgroups per CU at n = 4096).
+template <int DC, int DV, int RULE, bool EARLY, int VPT, int WPE>
+__global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
+    constexpr int CPT = VPT * DV / DC;
+    constexpr int kLdsVpt = VPT;  // shadows the namespace constant: everything below is written for VPT
+    static_assert(CPT * DC == VPT * DV && CPT % 2 == 0 && VPT % 4 == 0, "checks and variables are processed in pairs");
     extern __shared__ __align__(16) float smem[];
     float* msg = smem;                                        // [msg_words]
     uint32_t* bits = reinterpret_cast<uint32_t*>(smem + p.msg_words); // [nw], by VN position
@@ -295,14 +298,17 @@ __global__ void __launch_bounds__(512, WPE) bp_lds_kernel(LdsParams p) {
         synd = *red;
     }
 
-    // hard[frame][j] for j = 4 tt .. 4 tt + 3 and 4 (tt + nt) .. : n = 8 nt, both table reads go out together
+    // hard[frame][j] for j = 4 (tt + u nt) .. + 3, u = 0 .. VPT / 4 - 1: n = VPT nt, the table reads go out together
     {
         uint8_t* out = p.hard + frame * p.n;
         const int4* pos4 = reinterpret_cast<const int4*>(p.pos_of_var) + tt;
-        const int4 q0 = pos4[0], q1 = pos4[nt];
+        int4 q[VPT / 4];
+#pragma unroll
+        for (int u = 0; u < VPT / 4; ++u) q[u] = pos4[u * nt];
         auto bit = [&](int q) -> unsigned char { return (unsigned char)((bits[q >> 5] >> (q & 31)) & 1u); };
-        reinterpret_cast<uchar4*>(out)[tt] = make_uchar4(bit(q0.x), bit(q0.y), bit(q0.z), bit(q0.w));
-        reinterpret_cast<uchar4*>(out)[tt + nt] = make_uchar4(bit(q1.x), bit(q1.y), bit(q1.z), bit(q1.w));
+#pragma unroll
+        for (int u = 0; u < VPT / 4; ++u)
+            reinterpret_cast<uchar4*>(out)[tt + u * nt] = make_uchar4(bit(q[u].x), bit(q[u].y), bit(q[u].z), bit(q[u].w));
     }
     if (t == 0) {
         if (p.out_iters) p.out_iters[frame] = iters;
@@ -318,18 +324,20 @@ struct LdsLaunch {
     bool early;
     int frames_per_wg;  // frames one workgroup decodes in turn (>= 1; early termination only)
     int wpe;  // 4 or 6, see bp_lds_kernel
+    int vpt;  // variables per thread: kLdsVpt or kLdsVptWide
     int threads;
     size_t lds_bytes;
     hipStream_t stream;
 };
 
-template <int DC, int DV, int CPT>
+template <int DC, int DV, int VPT>
 inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
+    if (l.threads * VPT != p.n || l.threads > 4096 / VPT) return hipErrorInvalidConfiguration;
     const long long fpw = (l.early && l.frames_per_wg > 0) ? l.frames_per_wg : 1;
     const dim3 grid((unsigned)((p.frames + fpw - 1) / fpw)), block((unsigned)l.threads);
 #define LDPC_LDS2(R, E, W)                                                                                   \
     do {                                                                                                     \
-        auto k = bp_lds_kernel<DC, DV, R, E, CPT, W>;                                                        \
+        auto k = bp_lds_kernel<DC, DV, R, E, VPT, W>;                                                        \
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                            (int)l.lds_bytes);                                                \
         if (e != hipSuccess) return e;                                                                       \
@@ -337,7 +345,8 @@ inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
     } while (0)
 #define LDPC_LDS(R, E)                                                                                       \
     do {                                                                                                     \
-        if (l.wpe >= 6) LDPC_LDS2(R, E, 6); else LDPC_LDS2(R, E, 4);                                         \
+        if constexpr (VPT == kLdsVptWide) LDPC_LDS2(R, E, 3);                                                \
+        else if (l.wpe >= 6) LDPC_LDS2(R, E, 6); else LDPC_LDS2(R, E, 4);                                    \
     } while (0)
     switch (l.rule) {
         case kCnMinSum: if (l.early) LDPC_LDS(kCnMinSum, true); else LDPC_LDS(kCnMinSum, false); break;

@@ -3,7 +3,7 @@
 #include "bp_lds.hpp"
 
 namespace ldpc {
-hipError_t bp_lds_launch_8_2(const LdsLaunch& l, const LdsParams& p) { return bp_lds_launch_impl<8, 2, 2>(l, p); }
+hipError_t bp_lds_launch_8_2(const LdsLaunch& l, const LdsParams& p) { return bp_lds_launch_impl<8, 2, kLdsVpt>(l, p); }
 unsigned bp_lds_8_2_params_bytes() { return (unsigned)sizeof(LdsParams); }
 
 }  // namespace ldpc

@@ -31,7 +31,7 @@ struct Options {
     int sim_overlap = 1;
     int verbose = 0;
     int lds_wpe = 0, lds_fpw = 0, generic_lds_kb = 0, nodes_blocks = 0, fpl = 0, layout = 0, rows_waves = 0, wps = 0,
-        nopipe = 0, rows_fused = -1, generic_threads = 0;
+        nopipe = 0, rows_fused = -1, generic_threads = 0, lds_vpt = 0;
     int test_nodes_oversize = 0;
 };
 
@@ -564,12 +564,15 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     // Frame-resident engine: regular code whose messages fit at least twice into a CU's LDS.
     if (!noalloc) {
         const bool shape = (c->reg_dc == 6 && c->reg_dv == 3) || (c->reg_dc == 8 && c->reg_dv == 2);
-        // exact tiling: 8 variables and 8 m / n checks per thread, whole wavefronts
-        const int nt = n / kLdsVpt;
+        // exact tiling: 8 variables and 8 m / n checks per thread, whole wavefronts; the (6,3) kernels also exist
+        // with 16 variables per thread (half the threads)
+        int vpt = kLdsVpt;
+        if (c->opt.lds_vpt == kLdsVptWide && c->reg_dc == 6 && n % (kLdsVptWide * 64) == 0) vpt = kLdsVptWide;
+        const int nt = n / vpt;
         // messages | packed decisions | accumulator | one syndrome bit per check
         const size_t msg_words = (size_t)(c->m / 2) * (size_t)lds_pair_stride(std::max(c->reg_dc, 2));
         const size_t lds_bytes = (msg_words + (size_t)c->nw + 4 + (size_t)(c->m + 31) / 32) * sizeof(float);
-        bool use = shape && n % (kLdsVpt * 64) == 0 && nt <= 512 && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll &&
+        bool use = shape && n % (vpt * 64) == 0 && nt <= 4096 / vpt && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll &&
                    c->m <= 2048;  // the convergence test reads the syndrome words with one wavefront
         if (c->opt.engine != LDPC_AMD_ENGINE_AUTO) use = false;
         if (use) {
@@ -586,7 +589,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             LdsLaunch l;
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
                      : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
-            l.early = early; l.threads = nt; l.lds_bytes = lds_bytes; l.stream = s;
+            l.early = early; l.threads = nt; l.vpt = vpt; l.lds_bytes = lds_bytes; l.stream = s;
             // measured: three workgroups per CU (80 registers) pay off for the (6,3) kernels; the (8,2)
             // kernels lose more to register spills than they gain in occupancy
             l.wpe = c->reg_dc == 6 ? 6 : 4;
@@ -1204,6 +1207,7 @@ int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
         case LDPC_AMD_OPT_TUNE_WPS: if (!(value == 0 || value == 2 || value == 4)) break; o.wps = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_NOPIPE: if (!range(0, 1)) break; o.nopipe = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_ROWS_FUSED: if (!range(-1, 1)) break; o.rows_fused = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_LDS_VPT: if (!(value == 0 || value == 8 || value == 16)) break; o.lds_vpt = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: if (!(value == 0 || (value >= 64 && value <= 512 && value % 64 == 0))) break; o.generic_threads = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: if (!range(0, 1)) break; o.test_nodes_oversize = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_NODES_REFUSALS:
@@ -1235,6 +1239,7 @@ int ldpc_amd_get_option(const ldpc_amd_ctx* c, int32_t key, int64_t* value) {
         case LDPC_AMD_OPT_TUNE_NOPIPE: *value = o.nopipe; break;
         case LDPC_AMD_OPT_TUNE_ROWS_FUSED: *value = o.rows_fused; break;
         case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: *value = o.generic_threads; break;
+        case LDPC_AMD_OPT_TUNE_LDS_VPT: *value = o.lds_vpt; break;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: *value = o.test_nodes_oversize; break;
         case LDPC_AMD_OPT_NODES_REFUSALS: *value = c->nodes_refusals; break;
         case LDPC_AMD_OPT_NODES_LAST_HIP_ERROR: *value = c->nodes_last_error; break;

@@ -227,6 +227,18 @@ def test_engines_return_identical_bits(pkg, c1, c2, oracle, engine):
                     assert (x == y).all(), (early, L, kernel)
             pkg.capi.set_default_options()
             assert (a[2] > 0).any()
+            if c is c2:  # the second tiling of the (6,3) kernels: 16 variables per thread, tables rebuilt for it
+                pkg.capi.set_default_options(lds_vpt=16)
+                try:
+                    b = c["dec"].decode_batch(llr, L, early)
+                    assert c["dec"].last_decode_kernel() == "bp_lds_kernel"
+                finally:
+                    pkg.capi.set_default_options()
+                for x, y in zip(a, b):
+                    assert (x == y).all(), (early, L, "lds_vpt=16")
+                b = c["dec"].decode_batch(llr, L, early)   # and back
+                for x, y in zip(a, b):
+                    assert (x == y).all(), (early, L, "lds_vpt back to the default")
     # an irregular quasi-cyclic code: runs of equal-degree rows (grouped loads) next to single rows
     _, (m, n, rows, cols) = pkg.codes.nr_bg1_shaped(z=8, seed=5)
     dec = pkg.Decoder(m, n, rows, cols)
