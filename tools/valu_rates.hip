@@ -17,7 +17,7 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int REPS = 16384;
 
-enum Op { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, LOG, BFI, MIX, XOR, AND_OR, MUL, ADD, FMAC, CNDMASK, LDEXP, ADD_ABS, FMA_K, CMP_E64, CND_E64, CND_NEG, CMP_XOR_CND };
+enum Op { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, LOG, BFI, MIX, XOR, AND_OR, MUL, ADD, FMAC, CNDMASK, LDEXP, ADD_ABS, FMA_K, CMP_E64, CND_E64, CND_NEG };
 
 template <int OP>
 __global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, unsigned long long* ticks, float* sink, float seed) {
@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, unsign
     const float c1 = 0.999f, c2 = 0.0001f;
     const v2f p1 = v2f{0.999f, 0.998f}, p2 = v2f{0.0001f, 0.0002f};
     __syncthreads();
-    asm volatile("s_mov_b64 s[20:21], 0x5555\n\ts_mov_b64 s[24:25], 0x3333" : : : "s20", "s21", "s24", "s25");
+    asm volatile("s_mov_b64 s[20:21], 0x5555" : : : "s20", "s21");  // the lane mask of the select cases
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < REPS; ++r) {
@@ -54,9 +54,6 @@ __global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, unsign
             if constexpr (OP == CMP_E64) asm volatile("v_cmp_gt_i32_e64 s[20:21], 0, %0" : : "v"(x[i]) : "s20", "s21");
             if constexpr (OP == CND_E64) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x[i]) : "v"(c1));
             if constexpr (OP == CND_NEG) asm volatile("v_cndmask_b32_e64 %0, %0, -%0, s[20:21]" : "+v"(x[i]));
-            if constexpr (OP == CMP_XOR_CND)
-                asm volatile("v_cmp_gt_i32_e64 s[20:21], 0, %0\n\ts_xor_b64 s[22:23], s[20:21], s[24:25]\n\tv_cndmask_b32_e64 %0, %0, -%0, s[22:23]"
-                             : "+v"(x[i]) : : "s20", "s21", "s22", "s23");
             if constexpr (OP == MIX) {
                 // the mix of the check-node rule per pair of edges: 8 transcendentals, 12 packed, 2 bit operations
                 if (i < 8) {
@@ -148,6 +145,5 @@ int main() {
     run<CMP_E64>("v_cmp_gt_i32_e64 -> sgpr pair", 16, d_cycles, d_ticks, d_sink, cus);
     run<CND_E64>("v_cndmask_b32_e64, sgpr mask", 16, d_cycles, d_ticks, d_sink, cus);
     run<CND_NEG>("v_cndmask_b32_e64 x, -x, sgpr mask", 16, d_cycles, d_ticks, d_sink, cus);
-    run<CMP_XOR_CND>("v_cmp -> s_xor -> v_cndmask (2 VALU)", 32, d_cycles, d_ticks, d_sink, cus);
     return 0;
 }
