@@ -129,6 +129,9 @@ int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
                                         cost model (default), 0 = never, 1 = whenever the code allows */
 #define LDPC_AMD_OPT_SIM_OVERLAP 4   /* ldpc_amd_simulate: chunks alternate between two streams (default 1) */
 #define LDPC_AMD_OPT_VERBOSE 5       /* diagnostics on stderr */
+#define LDPC_AMD_OPT_SIM_FUSED 6     /* ldpc_amd_simulate: the frame-resident kernels of the (6,3) and (8,2) codes count
+                                        the errors themselves instead of writing hard words for a counting pass (default 1;
+                                        the counters are the same either way) */
 /* tuning knobs for measurements; 0 = the library's own choice */
 #define LDPC_AMD_OPT_TUNE_LDS_WPE 100        /* frame-resident kernels: wavefronts per SIMD compiled for (4 or 6) */
 #define LDPC_AMD_OPT_TUNE_LDS_FPW 101        /* ... frames one workgroup decodes in turn (early termination) */

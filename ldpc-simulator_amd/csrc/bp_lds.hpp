@@ -42,6 +42,12 @@ struct LdsParams {
     uint8_t* hard;         // [frames][n]
     int32_t* out_iters;    // [frames] or null
     int32_t* out_synd;     // [frames] or null
+    // Error accounting inside the kernel (a Monte-Carlo leg, COUNT kernels only): the decisions are compared with
+    // the transmitted word where they are formed and only the counters of count_errors_kernel leave the
+    // chip - no hard[] rows, no iteration and syndrome arrays, no second pass over the batch.
+    const uint8_t* cw;             // [frames][n] transmitted words, or null = the all-zero word
+    unsigned long long* counters;  // [16 + max_iters], added to with atomics
+    int count_rx;                  // also the channel-side counters (errors the channel made, bits decoded wrong that it had not touched)
 };
 
 // LDS slot of CSR edge e = (check i, position k): the rows of the two checks a thread processes
@@ -73,9 +79,11 @@ struct LdsNo { static constexpr bool value = false; };
 // VPT variables and CPT = VPT * DV / DC (even) checks per thread, exactly: n = VPT * blockDim.x, m = CPT * blockDim.x.
 // WPE = wavefronts per SIMD the register budget is set for.  VPT = 8: 6 (80 registers, three 8-wave workgroups
 // per CU) or 4 (128 registers, two).  VPT = 16: 3 (168 registers, three 4-wave workgroups per CU at n = 4096).
-template <int DC, int DV, int RULE, bool EARLY, int VPT, int WPE>
+// COUNT: error accounting in place of the outputs (LdsParams::counters; LDPC_GallagerIntStreamSimu.java:136-183).
+template <int DC, int DV, int RULE, bool EARLY, int VPT, int WPE, bool COUNT = false>
 __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
     constexpr int CPT = VPT * DV / DC;
+    static_assert(!COUNT || VPT == 8, "the accounting keeps three 8-bit masks of a thread's variables in one register");
     constexpr int kLdsVpt = VPT;  // shadows the namespace constant: everything below is written for VPT
     static_assert(CPT * DC == VPT * DV && CPT % 2 == 0 && VPT % 4 == 0, "checks and variables are processed in pairs");
     extern __shared__ __align__(16) float smem[];
@@ -108,8 +116,16 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
     // the addresses above are formed once for all of them, which counts when a frame takes a handful of
     // iterations.  At fixed iterations it takes one frame (the launch gives it no second one), and the
     // compiler sees a body that runs once and keeps nothing else alive across it.
+    // accounting: two sums per wavefront of the frame in flight, then the workgroup's share of the counters (flushed when it ends)
+    unsigned* fsum = reinterpret_cast<unsigned*>(red + 4 + ((p.m + 31) >> 5));
+    unsigned long long* wcnt = reinterpret_cast<unsigned long long*>(fsum + 2 * (4096 / 64 / VPT));
+    const int nc = 16 + p.max_iters;
+    if constexpr (COUNT)
+        for (int i = t; i < nc; i += nt) wcnt[i] = 0ull;
     for (long long frame = blockIdx.x; frame < p.frames; frame += gridDim.x) {
-    if (t == 0) *red = 0;
+    if (t == 0) {
+        *red = 0;
+    }
     // The syndrome is kept as one bit per check.  With early termination it is maintained every iteration
     // by toggling the checks of the variables whose decision changed since the previous one (few, after
     // the first iterations); at fixed iterations it is formed once at the end, from the variables decided
@@ -127,15 +143,33 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
     int tt = t;
     asm volatile("" : "+v"(tt));
     float lam8[kLdsVpt];
+    // accounting: bit v = transmitted bit of variable v, bit 8 + v = its received hard bit, bit 16 + v = it is an
+    // information position
+    uint32_t side = 0u;
     {
         const int* permp = p.perm + tt;
         int pj[kLdsVpt];
 #pragma unroll
         for (int v = 0; v < kLdsVpt; ++v) pj[v] = permp[v * nt];
+        uint8_t cb[kLdsVpt];
+        if constexpr (COUNT) {
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; ++v) cb[v] = 0;
+            if (p.cw) {
+                const uint8_t* src_cw = p.cw + frame * p.n;
+#pragma unroll
+                for (int v = 0; v < kLdsVpt; ++v) cb[v] = src_cw[pj[v]];
+            }
+        }
+        uint32_t rx = 0u;  // received hard bits: "llr < 0" of the caller's value, or the received word itself
         if (p.llr) {
             const float* src_llr = p.llr + frame * p.n;
 #pragma unroll
             for (int v = 0; v < kLdsVpt; ++v) lam8[v] = src_llr[pj[v]];
+            if constexpr (COUNT) {
+#pragma unroll
+                for (int v = 0; v < kLdsVpt; ++v) rx |= (lam8[v] < 0.0f ? 1u : 0u) << v;
+            }
 #pragma unroll
             for (int v = 0; v < kLdsVpt; ++v) lam8[v] *= p.scale;
         } else {
@@ -147,7 +181,14 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
             for (int v = 0; v < kLdsVpt; ++v) {
                 const float mag = (pj[v] < p.g_length) ? p.l0 : p.l1;
                 lam8[v] = (rb[v] == 0) ? mag : -mag;
+                if constexpr (COUNT) rx |= (rb[v] != 0 ? 1u : 0u) << v;
             }
+        }
+        if constexpr (COUNT) {
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; ++v) side |= (pj[v] < p.g_length ? 1u : 0u) << (16 + v) | (cb[v] != 0 ? 1u : 0u) << v;
+            side |= rx << 8;
+            asm volatile("" : "+v"(side));  // packed here, not where it is used: the loaded bytes must not live until then
         }
     }
     v2f vl[kLdsVpt / 2];
@@ -251,7 +292,11 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
             // "sumSyndro == 0" (LogDecoder.java:108-119): no bit set in any word.  Every wave scans all the
             // words for itself, so all reach the same verdict without a reduction or a second barrier (the
             // next toggles come after the barrier that ends the next check-node phase).
-            const uint32_t any = ((t & 63) < mw) ? par[t & 63] : 0u;  // m <= 2048 here: at most 64 words
+            // (the lane index afresh: the address of the word would otherwise sit in a register of its own for the
+            // whole decode, or in scratch memory)
+            int tl = t;
+            asm volatile("" : "+v"(tl));
+            const uint32_t any = ((tl & 63) < mw) ? par[tl & 63] : 0u;  // m <= 2048 here: at most 64 words
             const bool bad = __ballot(any != 0u) != 0ull;
             if (!bad) {
                 iters = it + 1;
@@ -269,7 +314,7 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
     }
     // decisions -> packed words by VN position: position t + v*nt of lane 0 of a wave is a multiple of 64, so its
     // word is (t >> 5) + v * (nt >> 5)
-    {
+    if constexpr (!COUNT) {
         unsigned long long mask[kLdsVpt];
 #pragma unroll
         for (int v = 0; v < kLdsVpt; ++v) mask[v] = __ballot((mydec >> v) & 1u);
@@ -298,6 +343,61 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
         synd = *red;
     }
 
+    if constexpr (COUNT) {
+        // The sums of count_errors_kernel from the masks every thread holds of its own variables: decisions that
+        // differ from the transmitted word at information / parity positions, channel errors at information
+        // positions, wrong decisions where the channel had made none.  Each at most 8 per thread and n per
+        // frame: two of them share a word.
+        const uint32_t sent = side & 0xffu;
+        const uint32_t chan = ((side >> 8) & 0xffu) ^ sent, info = side >> 16;
+        const uint32_t err = (mydec ^ sent) & 0xffu;
+        unsigned a = (unsigned)__popc(err & info) | (unsigned)__popc(err & ~info) << 16;
+        unsigned b = (unsigned)__popc(chan & info) | (unsigned)__popc(err & info & ~chan) << 16;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o);
+            b += __shfl_xor(b, o);
+        }
+        // the lane index afresh: addresses and lane tests formed from `t` would be hoisted out of the frame loop and
+        // live in registers through every iteration of every frame
+        int te = t;
+        asm volatile("" : "+v"(te));
+        if ((te & 63) == 0) {  // one slot per wavefront, plain stores
+            fsum[2 * (te >> 6)] = a;
+            fsum[2 * (te >> 6) + 1] = b;
+        }
+        __syncthreads();
+        // one counter per thread (one thread updating them all in turn holds a dozen 64-bit sums in registers
+        // at once, on top of everything that lives across frames)
+        if (te < 13) {
+            unsigned sa = 0u, sb = 0u;
+            for (int w = 0; w < (nt >> 6); ++w) {
+                sa += fsum[2 * w];
+                sb += fsum[2 * w + 1];
+            }
+            const unsigned e_info = sa & 0xffffu, e_chk = sa >> 16, ch = sb & 0xffffu, mis = sb >> 16;
+            const bool correct = (e_info + e_chk) == 0u;
+            const unsigned rxc = p.count_rx ? 1u : 0u;
+            unsigned long long inc = 1ull;                                         // 0: frames
+            inc = te == 1 ? (correct ? 0u : 1u) : inc;                              // 1: frame errors
+            inc = te == 2 ? e_info : inc;                                           // 2: information bit errors
+            inc = te == 3 ? e_chk : inc;                                            // 3: parity bit errors
+            inc = te == 4 ? (e_info ? 1u : 0u) : inc;                               // 4, 5: frames with such errors
+            inc = te == 5 ? (e_chk ? 1u : 0u) : inc;
+            inc = te == 6 ? ((synd == 0 && !correct) ? 1u : 0u) : inc;              // 6: undetected
+            inc = te == 7 ? mis * rxc : inc;                                        // 7: decoded wrong, received right
+            inc = te == 8 ? (correct ? (unsigned)iters : 0u) : inc;                 // 8, 9: iterations of right / wrong frames
+            inc = te == 9 ? (correct ? 0u : (unsigned)iters) : inc;
+            inc = te == 10 ? ch * rxc : inc;                                        // 10, 11: channel errors, squared
+            inc = te == 11 ? (unsigned long long)ch * ch * rxc : inc;
+            int slot = te;
+            if (te == 12) {                                                         // iteration histogram
+                slot = 16 + iters - 1;
+                if (iters < 1 || iters > p.max_iters) { slot = 12; inc = 0ull; }
+            }
+            wcnt[slot] += inc;
+        }
+    } else {
     // hard[frame][j] for j = 4 (tt + u nt) .. + 3, u = 0 .. VPT / 4 - 1: n = VPT nt, the table reads go out together
     {
         uint8_t* out = p.hard + frame * p.n;
@@ -314,8 +414,14 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
         if (p.out_iters) p.out_iters[frame] = iters;
         if (p.out_synd) p.out_synd[frame] = synd;
     }
+    }
     if constexpr (!EARLY) break;
     __syncthreads();  // the next frame reuses the LDS
+    }
+    if constexpr (COUNT) {
+        __syncthreads();
+        for (int i = t; i < nc; i += nt)
+            if (wcnt[i]) atomicAdd(&p.counters[i], wcnt[i]);
     }
 }
 
@@ -325,6 +431,7 @@ struct LdsLaunch {
     int frames_per_wg;  // frames one workgroup decodes in turn (>= 1; early termination only)
     int wpe;  // 4 or 6, see bp_lds_kernel
     int vpt;  // variables per thread: kLdsVpt or kLdsVptWide
+    bool count;  // error accounting inside the kernel (default check-node rule, 8 variables per thread)
     int threads;
     size_t lds_bytes;
     hipStream_t stream;
@@ -335,9 +442,9 @@ inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
     if (l.threads * VPT != p.n || l.threads > 4096 / VPT) return hipErrorInvalidConfiguration;
     const long long fpw = (l.early && l.frames_per_wg > 0) ? l.frames_per_wg : 1;
     const dim3 grid((unsigned)((p.frames + fpw - 1) / fpw)), block((unsigned)l.threads);
-#define LDPC_LDS2(R, E, W)                                                                                   \
+#define LDPC_LDS2(R, E, W, ...)                                                                              \
     do {                                                                                                     \
-        auto k = bp_lds_kernel<DC, DV, R, E, VPT, W>;                                                        \
+        auto k = bp_lds_kernel<DC, DV, R, E, VPT, W, ##__VA_ARGS__>;                                         \
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                            (int)l.lds_bytes);                                                \
         if (e != hipSuccess) return e;                                                                       \
@@ -348,6 +455,16 @@ inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
         if constexpr (VPT == kLdsVptWide) LDPC_LDS2(R, E, 3);                                                \
         else if (l.wpe >= 6) LDPC_LDS2(R, E, 6); else LDPC_LDS2(R, E, 4);                                    \
     } while (0)
+    if (l.count) {
+        if constexpr (VPT == kLdsVpt) {
+            if (l.rule != kCnComplement || !p.counters) return hipErrorInvalidValue;
+            if (l.early) { if (l.wpe >= 6) LDPC_LDS2(kCnComplement, true, 6, true); else LDPC_LDS2(kCnComplement, true, 4, true); }
+            else { if (l.wpe >= 6) LDPC_LDS2(kCnComplement, false, 6, true); else LDPC_LDS2(kCnComplement, false, 4, true); }
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     switch (l.rule) {
         case kCnMinSum: if (l.early) LDPC_LDS(kCnMinSum, true); else LDPC_LDS(kCnMinSum, false); break;
         case kCnSumProduct: if (l.early) LDPC_LDS(kCnSumProduct, true); else LDPC_LDS(kCnSumProduct, false); break;

@@ -29,6 +29,7 @@ struct Options {
     int stream_kernel = 0;
     int nodes = -1;
     int sim_overlap = 1;
+    int sim_fused = 1;
     int verbose = 0;
     int lds_wpe = 0, lds_fpw = 0, generic_lds_kb = 0, nodes_blocks = 0, fpl = 0, layout = 0, rows_waves = 0, wps = 0,
         nopipe = 0, rows_fused = -1, generic_threads = 0, lds_vpt = 0;
@@ -505,6 +506,14 @@ struct SrcArgs {
     const uint8_t* r;
     double l0, l1;  // BSC magnitudes in nats, double as the reference forms them
 };
+// Error accounting asked of the decode launch itself (ldpc_amd_simulate): the engines that can do it set `done`
+// and write no hard words, iteration counts or syndrome weights; the others ignore it.
+struct CountArgs {
+    const uint8_t* cw;             // transmitted words, null = the all-zero word
+    unsigned long long* counters;  // device, 16 + max_iters
+    bool rx;                       // channel-side counters too
+    bool done;
+};
 
 // LLR unit of the selected check-node rule (see bp_kernels.hpp): bits for the default sum-product rule, nats otherwise.
 double llr_scale(const ldpc_amd_ctx* c) {
@@ -548,7 +557,7 @@ size_t stream_tile_bytes(const ldpc_amd_ctx* c, int T) {
 
 // noalloc: run the sweep launches on the static scratch array and call nothing that allocates.
 int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_iters, int early_term, uint8_t* d_hard,
-               int32_t* d_iters, int32_t* d_synd, hipStream_t s, bool noalloc = false) {
+               int32_t* d_iters, int32_t* d_synd, hipStream_t s, bool noalloc = false, CountArgs* count = nullptr) {
     if (frames < 0 || max_iters < 0 || !d_hard) return fail(c, LDPC_AMD_EINVAL, "decode: bad argument");
     c->timed_launches = 0;
     c->timed_frames = 0;
@@ -571,7 +580,12 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         const int nt = n / vpt;
         // messages | packed decisions | accumulator | one syndrome bit per check
         const size_t msg_words = (size_t)(c->m / 2) * (size_t)lds_pair_stride(std::max(c->reg_dc, 2));
-        const size_t lds_bytes = (msg_words + (size_t)c->nw + 4 + (size_t)(c->m + 31) / 32) * sizeof(float);
+        // accounting inside the kernel: the default rule at 8 variables per thread; two sums of the frame in flight
+        // and the workgroup's counters (64-bit) follow the syndrome bits
+        const bool counting = count && count->counters && c->opt.sim_fused && vpt == kLdsVpt && max_iters <= 1024 &&
+                              c->cn_rule != LDPC_AMD_CN_MINSUM && c->cn_rule != LDPC_AMD_CN_SUMPRODUCT_TANH;
+        const size_t lds_bytes = (msg_words + (size_t)c->nw + 4 + (size_t)(c->m + 31) / 32 +
+                                  (counting ? 2 + 2 * (size_t)(16 + max_iters) : 0)) * sizeof(float);
         bool use = shape && n % (vpt * 64) == 0 && nt <= 4096 / vpt && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll &&
                    c->m <= 2048;  // the convergence test reads the syndrome words with one wavefront
         if (c->opt.engine != LDPC_AMD_ENGINE_AUTO) use = false;
@@ -586,7 +600,9 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             q.scale = (float)llr_scale(c);
             q.frames = frames; q.max_iters = max_iters;
             q.hard = d_hard; q.out_iters = d_iters; q.out_synd = d_synd;
+            if (counting) { q.cw = count->cw; q.counters = count->counters; q.count_rx = count->rx ? 1 : 0; }
             LdsLaunch l;
+            l.count = counting;
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
                      : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
             l.early = early; l.threads = nt; l.vpt = vpt; l.lds_bytes = lds_bytes; l.stream = s;
@@ -609,6 +625,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             c->timed_launches = 1;
             c->timed_frames = frames;
             c->last_kernel = "bp_lds_kernel";
+            if (counting) count->done = true;
             return LDPC_AMD_OK;
         }
     }
@@ -1196,6 +1213,7 @@ int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
             c->nodes_refused_in_a_row = 0;
             return LDPC_AMD_OK;
         case LDPC_AMD_OPT_SIM_OVERLAP: if (!range(0, 1)) break; o.sim_overlap = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_SIM_FUSED: if (!range(0, 1)) break; o.sim_fused = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_VERBOSE: if (!range(0, 1)) break; o.verbose = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_LDS_WPE: if (!(value == 0 || value == 4 || value == 6)) break; o.lds_wpe = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_LDS_FPW: if (!range(0, 1 << 20)) break; o.lds_fpw = v; return LDPC_AMD_OK;
@@ -1227,6 +1245,7 @@ int ldpc_amd_get_option(const ldpc_amd_ctx* c, int32_t key, int64_t* value) {
         case LDPC_AMD_OPT_STREAM_KERNEL: *value = o.stream_kernel; break;
         case LDPC_AMD_OPT_NODES: *value = o.nodes; break;
         case LDPC_AMD_OPT_SIM_OVERLAP: *value = o.sim_overlap; break;
+        case LDPC_AMD_OPT_SIM_FUSED: *value = o.sim_fused; break;
         case LDPC_AMD_OPT_VERBOSE: *value = o.verbose; break;
         case LDPC_AMD_OPT_TUNE_LDS_WPE: *value = o.lds_wpe; break;
         case LDPC_AMD_OPT_TUNE_LDS_FPW: *value = o.lds_fpw; break;
@@ -1490,11 +1509,15 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
             src = SrcArgs{Src::Bsc, nullptr, (const uint8_t*)st[0], l0, l1};
         }
         if (rc) return rc;
-        rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)st[1], (int32_t*)st[2], (int32_t*)st[3], s);
+        // the frame-resident kernels of the (6,3) and (8,2) codes count the errors themselves; for every other
+        // engine the accounting is a pass of its own over the decoder's outputs
+        CountArgs count{cw, c->d_counters, true, false};
+        rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)st[1], (int32_t*)st[2], (int32_t*)st[3], s, false, &count);
         if (rc) return rc;
-        rc = count_launch(c, nf, (const uint8_t*)st[1], cw, awgn ? nullptr : (const uint8_t*)st[0],
-                          awgn ? (const float*)st[0] : nullptr, (const int32_t*)st[2], (const int32_t*)st[3], max_iters,
-                          c->d_counters, s);
+        if (!count.done)
+            rc = count_launch(c, nf, (const uint8_t*)st[1], cw, awgn ? nullptr : (const uint8_t*)st[0],
+                              awgn ? (const float*)st[0] : nullptr, (const int32_t*)st[2], (const int32_t*)st[3], max_iters,
+                              c->d_counters, s);
         if (rc) return rc;
         if (index == 0) {
             const char* k = c->last_kernel;

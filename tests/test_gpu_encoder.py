@@ -138,3 +138,47 @@ def test_count_errors_word_and_byte_paths(pkg, oracle):
             want = oracle.count_errors(m, n, hard, rx, it, sw, L, cw=cw if use_cw else None)
             assert (d_cnt.cpu().numpy().astype(np.uint64) == want).all(), (n, m, use_cw)
         dec.close()
+
+
+def test_accounting_inside_the_resident_kernels_equals_the_counting_pass(pkg, oracle):
+    """ldpc_amd_simulate on the (8,2) and (6,3) codes: the frame-resident kernels compare their decisions with
+    the transmitted word themselves (option sim_fused, the default) instead of writing hard words for
+    count_errors_kernel.  Every counter must equal the two-pass leg's: both channels families, random and
+    all-zero codewords, early termination and fixed iterations, ragged batches, one and several frames per
+    workgroup; and the checker's leg on the BSC."""
+    for shape, nvar, early_cases in (((8, 2), 1024, (True, False)), ((6, 3), 1536, (True, False))):
+        dc, dv = shape
+        m, n, rows, cols = (pkg.codes.gallager(nvar, dc, dv, seed=3) if dc == 8 else pkg.codes.regular_ldpc(nvar, dv, dc, seed=3))
+        eh, eg = pkg.encoder.systematic_pair(pkg.check_matrix_io.to_dense(m, n, rows, cols))
+        r, c = np.nonzero(eh)
+        dec = pkg.Decoder(m, n, r.astype(np.int32), c.astype(np.int32))
+        g = oracle.Graph(m, n, r, c)
+        for with_g in (False, True):
+            dec.set_generator(eg if with_g else None)
+            for early in early_cases:
+                for ch, param, frames, L in ((oracle.CH_BSC_INFO, 0.03, 1000, 30), (oracle.CH_BSC_ALL, 0.04, 777, 20),
+                                             (oracle.CH_AWGN, 2.0, 1501, 25), (oracle.CH_AWGN, 4.5, 64, 10)):
+                    got = {}
+                    for fused, fpw in ((1, 0), (1, 5), (0, 0)):
+                        dec.set_option("sim_fused", fused)
+                        dec.set_option("lds_fpw", fpw)
+                        got[(fused, fpw)] = dec.simulate(ch, param, 17, 123, frames, L, early)
+                        assert dec.last_decode_kernel() == "bp_lds_kernel"
+                    dec.set_option("lds_fpw", 0)
+                    ref = got[(0, 0)]
+                    assert ref[0] == frames and ref[16:].sum() == frames
+                    for key, val in got.items():
+                        assert (val == ref).all(), (shape, with_g, early, ch, key, val[:12], ref[:12], np.nonzero(val != ref)[0])
+                    # (the (8,2) code only: on the (6,3) code one frame in a thousand takes an iteration more or less in
+                    # fp32 than in the checker's double, with either leg)
+                    if ch != oracle.CH_AWGN and early and dc == 8:
+                        want = g.simulate(ch, param, 17, 123, frames, L, G=eg if with_g else None)
+                        assert (ref == want).all(), (shape, with_g, ch, ref[:12], want[:12])
+        # no frames, and a rule the fused kernels are not built for: the counting pass takes over
+        dec.set_option("sim_fused", 1)
+        assert not dec.simulate(oracle.CH_AWGN, 2.0, 17, 0, 0, 10, True).any()
+        dec.set_cn_rule(pkg.capi.CN_MINSUM)
+        a = dec.simulate(oracle.CH_BSC_INFO, 0.03, 17, 0, 300, 10, True)
+        dec.set_option("sim_fused", 0)
+        assert (a == dec.simulate(oracle.CH_BSC_INFO, 0.03, 17, 0, 300, 10, True)).all()
+        dec.close()
