@@ -17,7 +17,7 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int REPS = 16384;
 
-enum Op { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, LOG, BFI, MIX, XOR, AND_OR, MUL, ADD, FMAC, CNDMASK, LDEXP, ADD_ABS, FMA_K, CMP_E64, CND_E64, CND_NEG };
+enum Op { FMA, PK_FMA, PK_MUL, PK_ADD, EXP, RCP, LOG, BFI, MIX, XOR, AND_OR, MUL, ADD, FMAC, CNDMASK, LDEXP, ADD_ABS, FMA_K, CMP_E64, CND_E64, CND_NEG, CMP_E32, CND_VCC_SET, CND_E64_VCC, MED3, AND2, ASHR, CMP_F32_E32, PAIR_E64, PAIR_VCC, XOR_LIT };
 
 template <int OP>
 __global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, unsigned long long* ticks, float* sink, float seed) {
@@ -29,6 +29,7 @@ __global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, unsign
     const v2f p1 = v2f{0.999f, 0.998f}, p2 = v2f{0.0001f, 0.0002f};
     __syncthreads();
     asm volatile("s_mov_b64 s[20:21], 0x5555" : : : "s20", "s21");  // the lane mask of the select cases
+    asm volatile("s_mov_b64 vcc, 0x5555" : : : "vcc");
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < REPS; ++r) {
@@ -54,6 +55,17 @@ __global__ void __launch_bounds__(256) rate_k(unsigned long long* cycles, unsign
             if constexpr (OP == CMP_E64) asm volatile("v_cmp_gt_i32_e64 s[20:21], 0, %0" : : "v"(x[i]) : "s20", "s21");
             if constexpr (OP == CND_E64) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x[i]) : "v"(c1));
             if constexpr (OP == CND_NEG) asm volatile("v_cndmask_b32_e64 %0, %0, -%0, s[20:21]" : "+v"(x[i]));
+            if constexpr (OP == CMP_E32) asm volatile("v_cmp_gt_i32_e32 vcc, 0, %0" : : "v"(x[i]) : "vcc");
+            if constexpr (OP == CMP_F32_E32) asm volatile("v_cmp_gt_f32_e32 vcc, 0, %0" : : "v"(x[i]) : "vcc");
+            if constexpr (OP == CND_VCC_SET) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(c1));
+            if constexpr (OP == CND_E64_VCC) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(c1));
+            if constexpr (OP == MED3) asm volatile("v_med3_f32 %0, %0, -%0, %1" : "+v"(x[i]) : "v"(c1));
+            if constexpr (OP == AND2) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x[i]) : "v"(c1));
+            if constexpr (OP == ASHR) asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(x[i]));
+            if constexpr (OP == XOR_LIT) asm volatile("v_xor_b32 %0, 0x80000000, %0" : "+v"(x[i]));
+            // a sign the way the check-node rule handles it: compare into a mask, mask product on the scalar unit, select
+            if constexpr (OP == PAIR_E64) asm volatile("v_cmp_gt_i32_e64 s[22:23], 0, %0\n\ts_xor_b64 s[24:25], s[22:23], s[20:21]\n\tv_cndmask_b32_e64 %0, %0, -%0, s[24:25]" : "+v"(x[i]) : : "s22", "s23", "s24", "s25", "scc");
+            if constexpr (OP == PAIR_VCC) asm volatile("v_cmp_gt_i32_e32 vcc, 0, %0\n\ts_xor_b64 vcc, vcc, s[20:21]\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(c1) : "vcc", "scc");
             if constexpr (OP == MIX) {
                 // the mix of the check-node rule per pair of edges: 8 transcendentals, 12 packed, 2 bit operations
                 if (i < 8) {
@@ -145,5 +157,15 @@ int main() {
     run<CMP_E64>("v_cmp_gt_i32_e64 -> sgpr pair", 16, d_cycles, d_ticks, d_sink, cus);
     run<CND_E64>("v_cndmask_b32_e64, sgpr mask", 16, d_cycles, d_ticks, d_sink, cus);
     run<CND_NEG>("v_cndmask_b32_e64 x, -x, sgpr mask", 16, d_cycles, d_ticks, d_sink, cus);
+    run<CMP_E32>("v_cmp_gt_i32_e32 -> vcc", 16, d_cycles, d_ticks, d_sink, cus);
+    run<CMP_F32_E32>("v_cmp_gt_f32_e32 -> vcc", 16, d_cycles, d_ticks, d_sink, cus);
+    run<CND_VCC_SET>("v_cndmask_b32_e32, vcc set before", 16, d_cycles, d_ticks, d_sink, cus);
+    run<CND_E64_VCC>("v_cndmask_b32_e64, vcc", 16, d_cycles, d_ticks, d_sink, cus);
+    run<MED3>("v_med3_f32 x, -x, c", 16, d_cycles, d_ticks, d_sink, cus);
+    run<AND2>("v_and_b32 (VOP2)", 16, d_cycles, d_ticks, d_sink, cus);
+    run<ASHR>("v_ashrrev_i32 (VOP2)", 16, d_cycles, d_ticks, d_sink, cus);
+    run<XOR_LIT>("v_xor_b32 literal", 16, d_cycles, d_ticks, d_sink, cus);
+    run<PAIR_E64>("cmp_e64 + s_xor + cndmask_e64 (2 VALU)", 32, d_cycles, d_ticks, d_sink, cus);
+    run<PAIR_VCC>("cmp_e32 + s_xor vcc + cndmask_e32 (2 VALU)", 32, d_cycles, d_ticks, d_sink, cus);
     return 0;
 }
