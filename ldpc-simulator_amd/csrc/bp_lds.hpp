@@ -25,7 +25,8 @@ constexpr int kLdsVpt = 8;   // variables per thread; threads per frame = n / 8,
 constexpr int kLdsVptWide = 16;  // the second tiling: half as many threads per frame, each with twice the nodes
 
 struct LdsParams {
-    int m, n, nw;
+    int m, n, nw;          // n: the caller's code length (stride of its frames); m, nw: checks and decision words of the
+                           // tiling, which is larger than the code when n is not (variables per thread) x blockDim.x
     long long E;
     int msg_words;         // floats of LDS the messages take: (m / 2) * lds_pair_stride(DC)
     // Tables built once per code on the host (ldpc_amd.hip, build_resident_tables):
@@ -83,7 +84,7 @@ struct LdsNo { static constexpr bool value = false; };
 template <int DC, int DV, int RULE, bool EARLY, int VPT, int WPE, bool COUNT = false>
 __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
     constexpr int CPT = VPT * DV / DC;
-    static_assert(!COUNT || VPT == 8, "the accounting keeps three 8-bit masks of a thread's variables in one register");
+    static_assert(!COUNT || VPT <= 8, "the accounting keeps three 8-bit masks of a thread's variables in one register");
     constexpr int kLdsVpt = VPT;  // shadows the namespace constant: everything below is written for VPT
     static_assert(CPT * DC == VPT * DV && CPT % 2 == 0 && VPT % 4 == 0, "checks and variables are processed in pairs");
     extern __shared__ __align__(16) float smem[];
@@ -151,6 +152,10 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
         int pj[kLdsVpt];
 #pragma unroll
         for (int v = 0; v < kLdsVpt; ++v) pj[v] = permp[v * nt];
+        // a variable past the end of the code (a code tiled as a larger one) reads nothing: positive LLR, bit 0
+        int pr[kLdsVpt];
+#pragma unroll
+        for (int v = 0; v < kLdsVpt; ++v) pr[v] = pj[v] < p.n ? pj[v] : 0;
         uint8_t cb[kLdsVpt];
         if constexpr (COUNT) {
 #pragma unroll
@@ -158,14 +163,18 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
             if (p.cw) {
                 const uint8_t* src_cw = p.cw + frame * p.n;
 #pragma unroll
-                for (int v = 0; v < kLdsVpt; ++v) cb[v] = src_cw[pj[v]];
+                for (int v = 0; v < kLdsVpt; ++v) cb[v] = src_cw[pr[v]];
+#pragma unroll
+                for (int v = 0; v < kLdsVpt; ++v) cb[v] = pj[v] < p.n ? cb[v] : (uint8_t)0;
             }
         }
         uint32_t rx = 0u;  // received hard bits: "llr < 0" of the caller's value, or the received word itself
         if (p.llr) {
             const float* src_llr = p.llr + frame * p.n;
 #pragma unroll
-            for (int v = 0; v < kLdsVpt; ++v) lam8[v] = src_llr[pj[v]];
+            for (int v = 0; v < kLdsVpt; ++v) lam8[v] = src_llr[pr[v]];
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; ++v) lam8[v] = pj[v] < p.n ? lam8[v] : 8.0f;
             if constexpr (COUNT) {
 #pragma unroll
                 for (int v = 0; v < kLdsVpt; ++v) rx |= (lam8[v] < 0.0f ? 1u : 0u) << v;
@@ -176,7 +185,9 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
             const uint8_t* src_r = p.r + frame * p.n;
             uint8_t rb[kLdsVpt];
 #pragma unroll
-            for (int v = 0; v < kLdsVpt; ++v) rb[v] = src_r[pj[v]];
+            for (int v = 0; v < kLdsVpt; ++v) rb[v] = src_r[pr[v]];
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; ++v) rb[v] = pj[v] < p.n ? rb[v] : (uint8_t)0;
 #pragma unroll
             for (int v = 0; v < kLdsVpt; ++v) {
                 const float mag = (pj[v] < p.g_length) ? p.l0 : p.l1;
@@ -408,7 +419,8 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
         auto bit = [&](int q) -> unsigned char { return (unsigned char)((bits[q >> 5] >> (q & 31)) & 1u); };
 #pragma unroll
         for (int u = 0; u < VPT / 4; ++u)
-            reinterpret_cast<uchar4*>(out)[tt + u * nt] = make_uchar4(bit(q[u].x), bit(q[u].y), bit(q[u].z), bit(q[u].w));
+            if (4 * (tt + u * nt) < p.n)  // n is a multiple of 4; past it lie the dummy variables of a tiled code
+                reinterpret_cast<uchar4*>(out)[tt + u * nt] = make_uchar4(bit(q[u].x), bit(q[u].y), bit(q[u].z), bit(q[u].w));
     }
     if (t == 0) {
         if (p.out_iters) p.out_iters[frame] = iters;
@@ -439,7 +451,7 @@ struct LdsLaunch {
 
 template <int DC, int DV, int VPT>
 inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
-    if (l.threads * VPT != p.n || l.threads > 4096 / VPT) return hipErrorInvalidConfiguration;
+    if (l.threads * VPT < p.n || l.threads > 4096 / VPT || l.threads % 64) return hipErrorInvalidConfiguration;
     const long long fpw = (l.early && l.frames_per_wg > 0) ? l.frames_per_wg : 1;
     const dim3 grid((unsigned)((p.frames + fpw - 1) / fpw)), block((unsigned)l.threads);
 #define LDPC_LDS2(R, E, W, ...)                                                                              \
@@ -456,7 +468,7 @@ inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
         else if (l.wpe >= 6) LDPC_LDS2(R, E, 6); else LDPC_LDS2(R, E, 4);                                    \
     } while (0)
     if (l.count) {
-        if constexpr (VPT == kLdsVpt) {
+        if constexpr (VPT <= kLdsVpt) {
             if (l.rule != kCnComplement || !p.counters) return hipErrorInvalidValue;
             if (l.early) { if (l.wpe >= 6) LDPC_LDS2(kCnComplement, true, 6, true); else LDPC_LDS2(kCnComplement, true, 4, true); }
             else { if (l.wpe >= 6) LDPC_LDS2(kCnComplement, false, 6, true); else LDPC_LDS2(kCnComplement, false, 4, true); }
@@ -479,5 +491,9 @@ hipError_t bp_lds_launch_6_3(const LdsLaunch& l, const LdsParams& p);
 unsigned bp_lds_6_3_params_bytes();  // see bp_kernels.hpp
 unsigned bp_lds_8_2_params_bytes();
 hipError_t bp_lds_launch_8_2(const LdsLaunch& l, const LdsParams& p);
+unsigned bp_lds_8_4_params_bytes();
+hipError_t bp_lds_launch_8_4(const LdsLaunch& l, const LdsParams& p);
+unsigned bp_lds_10_5_params_bytes();
+hipError_t bp_lds_launch_10_5(const LdsLaunch& l, const LdsParams& p);
 
 }  // namespace ldpc

@@ -69,6 +69,7 @@ struct ldpc_amd_ctx {
     void* stage_cw = nullptr;
     size_t stage_cw_bytes = 0;
     // tables of the frame-resident engine (built on first use, see build_resident_tables)
+    int res_vpt = 0;
     int res_nt = 0;
     int* d_res = nullptr;  // perm[n] | pos_of_var[n] | vn_off[E]
     double res_conflict = 0.0;  // mean LDS bank multiplicity of the VN gathers (1 = conflict free)
@@ -219,15 +220,33 @@ struct PlaceRng {
 // (3,6) n = 4096: 103 of 128 groups conflict-free, mean worst multiplicity 2.10 -> 1.21.  The assignment only
 // changes which lane owns which variable and where a check's row lies; every variable still sums its own
 // edges in ascending check order and every check its own in ascending variable order.
-int build_resident_tables(ldpc_amd_ctx* c, int nt) {
-    if (c->d_res && c->res_nt == nt) return LDPC_AMD_OK;
-    const int n = c->n, m = c->m, dc = c->reg_dc, dv = c->reg_dv;
-    const long long E = c->E;
+//
+// Codes whose n is not (variables per thread) x (whole wavefronts) are tiled as a larger code: n2 = vpt * nt
+// variables and m2 = n2 * dv / dc checks, of which the last n2 - n and m2 - m form a regular graph of their own
+// (socket s = j' dv + k of dummy variable j' belongs to dummy check s mod (m2 - m), position s / (m2 - m) of its
+// row).  The kernels give the dummy variables a positive LLR: they decide 0 at once, their checks are satisfied
+// from the first iteration on, no message passes between them and the code, and their decisions are not
+// written.  Every table below is built for that larger graph.
+int build_resident_tables(ldpc_amd_ctx* c, int nt, int vpt) {
+    if (c->d_res && c->res_nt == nt && c->res_vpt == vpt) return LDPC_AMD_OK;
+    const int dc = c->reg_dc, dv = c->reg_dv;
+    const int n = vpt * nt, m = (int)((long long)n * dv / dc);
+    const long long E = (long long)n * dv;
+    const int pad_m = m - c->m;
+    if (n < c->n || m < c->m || (long long)m * dc != E || (n > c->n && pad_m < dv))
+        return fail(c, LDPC_AMD_EINVAL, "resident tables: the code does not tile");
+    std::vector<int> col_edge((size_t)E);  // edge ids (row-major positions in the larger graph) of every variable
+    std::copy(c->h_col_edge.begin(), c->h_col_edge.end(), col_edge.begin());
+    for (int j = c->n; j < n; ++j)
+        for (int k = 0; k < dv; ++k) {
+            const long long sock = (long long)(j - c->n) * dv + k;
+            col_edge[(size_t)j * dv + k] = (int)(((long long)c->m + sock % pad_m) * dc + sock / pad_m);
+        }
     const int target = n / 32;
     // coordinate of an edge: its rank among the edges of its variable
     std::vector<unsigned char> coord((size_t)E);
     for (int j = 0; j < n; ++j)
-        for (int k = 0; k < dv; ++k) coord[(size_t)c->h_col_edge[(size_t)j * dv + k]] = (unsigned char)k;
+        for (int k = 0; k < dv; ++k) coord[(size_t)col_edge[(size_t)j * dv + k]] = (unsigned char)k;
     // 1. rows of the checks
     std::vector<int> where((size_t)m);  // check i owns the row that check index where[i] has in lds_slot()
     for (int i = 0; i < m; ++i) where[(size_t)i] = i;
@@ -281,7 +300,7 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt) {
     // 2. lanes of the variables
     std::vector<unsigned char> bank((size_t)n * dv);
     for (int j = 0; j < n; ++j)
-        for (int k = 0; k < dv; ++k) bank[(size_t)j * dv + k] = (unsigned char)(slot[(size_t)c->h_col_edge[(size_t)j * dv + k]] & 31);
+        for (int k = 0; k < dv; ++k) bank[(size_t)j * dv + k] = (unsigned char)(slot[(size_t)col_edge[(size_t)j * dv + k]] & 31);
     std::vector<int> perm((size_t)n), pos((size_t)n);
     std::vector<char> taken((size_t)n, 0);
     int next_group = 0;
@@ -404,7 +423,7 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt) {
     for (int p = 0; p < n; ++p) {
         t_perm[p] = perm[(size_t)p];
         t_pos[p] = pos[(size_t)p];
-        for (int k = 0; k < dv; ++k) t_vn[(size_t)p * dv + k] = 4 * slot[(size_t)c->h_col_edge[(size_t)perm[(size_t)p] * dv + k]];
+        for (int k = 0; k < dv; ++k) t_vn[(size_t)p * dv + k] = 4 * slot[(size_t)col_edge[(size_t)perm[(size_t)p] * dv + k]];
     }
     if (c->d_res) {
         LDPC_HIP(c, hipFree(c->d_res));
@@ -413,9 +432,10 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt) {
     LDPC_HIP(c, hipMalloc((void**)&c->d_res, tab.size() * sizeof(int)));
     LDPC_HIP(c, hipMemcpy(c->d_res, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
     c->res_nt = nt;
+    c->res_vpt = vpt;
     if (c->opt.verbose)
-        fprintf(stderr, "ldpc_amd: resident tables nt=%d, mean worst bank multiplicity of VN gathers %.3f, %d of %d half wavefronts conflict-free\n",
-                nt, c->res_conflict, c->res_clean_groups, n / 32);
+        fprintf(stderr, "ldpc_amd: resident tables nt=%d, %d variables per thread (%d dummy variables), mean worst bank multiplicity of VN gathers %.3f, %d of %d half wavefronts conflict-free\n",
+                nt, vpt, n - c->n, c->res_conflict, c->res_clean_groups, n / 32);
     return LDPC_AMD_OK;
 }
 
@@ -572,28 +592,36 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     const bool early = early_term != 0;
     // Frame-resident engine: regular code whose messages fit at least twice into a CU's LDS.
     if (!noalloc) {
-        const bool shape = (c->reg_dc == 6 && c->reg_dv == 3) || (c->reg_dc == 8 && c->reg_dv == 2);
-        // exact tiling: 8 variables and 8 m / n checks per thread, whole wavefronts; the (6,3) kernels also exist
-        // with 16 variables per thread (half the threads)
-        int vpt = kLdsVpt;
-        if (c->opt.lds_vpt == kLdsVptWide && c->reg_dc == 6 && n % (kLdsVptWide * 64) == 0) vpt = kLdsVptWide;
-        const int nt = n / vpt;
+        const int dcr = c->reg_dc, dvr = c->reg_dv;
+        const bool shape = (dcr == 6 && dvr == 3) || (dcr == 8 && dvr == 2) || (dcr == 8 && dvr == 4) || (dcr == 10 && dvr == 5);
+        // vpt variables and vpt dv / dc checks per thread, whole wavefronts: 8 variables per thread, 4 for the (10,5)
+        // kernels; the (6,3) kernels also exist with 16 (half the threads).  A code whose n is not vpt x 64 x
+        // (wavefronts) is tiled as the next larger one with dummy nodes (build_resident_tables).
+        int vpt = (dcr == 10) ? 4 : kLdsVpt;
+        if (c->opt.lds_vpt == kLdsVptWide && dcr == 6 && n % (kLdsVptWide * 64) == 0) vpt = kLdsVptWide;
+        const int nt = shape ? (int)(((long long)n + vpt * 64 - 1) / (vpt * 64)) * 64 : 64;
+        const long long n2 = (long long)vpt * nt;
+        const long long m2 = shape ? n2 * dvr / dcr : 0;
+        const size_t nw2 = (size_t)(n2 / 32), mw2 = (size_t)((m2 + 31) / 32);
         // messages | packed decisions | accumulator | one syndrome bit per check
-        const size_t msg_words = (size_t)(c->m / 2) * (size_t)lds_pair_stride(std::max(c->reg_dc, 2));
-        // accounting inside the kernel: the default rule at 8 variables per thread; two sums of the frame in flight
-        // and the workgroup's counters (64-bit) follow the syndrome bits
-        const bool counting = count && count->counters && c->opt.sim_fused && vpt == kLdsVpt && max_iters <= 1024 &&
+        const size_t msg_words = (size_t)(m2 / 2) * (size_t)lds_pair_stride(std::max(dcr, 2));
+        // accounting inside the kernel: the default rule at up to 8 variables per thread; two sums per wavefront of the
+        // frame in flight and the workgroup's counters (64-bit) follow the syndrome bits
+        const bool counting = count && count->counters && c->opt.sim_fused && vpt <= kLdsVpt && max_iters <= 1024 &&
                               c->cn_rule != LDPC_AMD_CN_MINSUM && c->cn_rule != LDPC_AMD_CN_SUMPRODUCT_TANH;
-        const size_t lds_bytes = (msg_words + (size_t)c->nw + 4 + (size_t)(c->m + 31) / 32 +
-                                  (counting ? 2 + 2 * (size_t)(16 + max_iters) : 0)) * sizeof(float);
-        bool use = shape && n % (vpt * 64) == 0 && nt <= 4096 / vpt && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll &&
-                   c->m <= 2048;  // the convergence test reads the syndrome words with one wavefront
+        const size_t lds_bytes = (msg_words + nw2 + 4 + mw2 +
+                                  (counting ? 2 * (size_t)(4096 / 64 / vpt) + 2 * (size_t)(16 + max_iters) : 0)) * sizeof(float);
+        bool use = shape && nt <= 4096 / vpt && lds_bytes <= 80 * 1024 && frames <= 0x7fffffffll &&
+                   (n2 * dvr) % dcr == 0 && m2 % 32 == 0 && n % 4 == 0 &&  // whole syndrome words, hard words stored four at a time
+                   (n2 == n || m2 - c->m >= dvr) &&
+                   m2 <= 2048;  // the convergence test reads the syndrome words with one wavefront
         if (c->opt.engine != LDPC_AMD_ENGINE_AUTO) use = false;
         if (use) {
-            if (int rc = build_resident_tables(c, nt)) return rc;
+            if (int rc = build_resident_tables(c, nt, vpt)) return rc;
             LdsParams q{};
-            q.m = c->m; q.n = n; q.nw = c->nw; q.E = c->E; q.msg_words = (int)msg_words;
-            q.perm = c->d_res; q.pos_of_var = q.perm + n; q.vn_off = q.pos_of_var + n;
+            // m and nw of the tiled code, n of the caller's (the stride of its frames)
+            q.m = (int)m2; q.n = n; q.nw = (int)nw2; q.E = n2 * dvr; q.msg_words = (int)msg_words;
+            q.perm = c->d_res; q.pos_of_var = q.perm + n2; q.vn_off = q.pos_of_var + n2;
             q.llr = src.kind == Src::Float ? src.llr : nullptr;
             q.r = src.kind == Src::Bsc ? src.r : nullptr;
             q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
@@ -608,7 +636,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             l.early = early; l.threads = nt; l.vpt = vpt; l.lds_bytes = lds_bytes; l.stream = s;
             // measured: three workgroups per CU (80 registers) pay off for the (6,3) kernels; the (8,2)
             // kernels lose more to register spills than they gain in occupancy
-            l.wpe = c->reg_dc == 6 ? 6 : 4;
+            l.wpe = dcr == 6 ? 6 : 4;
             if (c->opt.lds_wpe) l.wpe = c->opt.lds_wpe;
             // with early termination a workgroup takes several frames in turn, once there are enough of
             // them to keep every CU supplied with workgroups that finish at different times
@@ -620,7 +648,8 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
                 c->ev.push_back(e);
             }
             LDPC_HIP(c, hipEventRecord(c->ev[0], s));
-            LDPC_HIP(c, c->reg_dc == 6 ? bp_lds_launch_6_3(l, q) : bp_lds_launch_8_2(l, q));
+            LDPC_HIP(c, dcr == 6 ? bp_lds_launch_6_3(l, q) : dcr == 10 ? bp_lds_launch_10_5(l, q)
+                                 : dvr == 4 ? bp_lds_launch_8_4(l, q) : bp_lds_launch_8_2(l, q));
             LDPC_HIP(c, hipEventRecord(c->ev[1], s));
             c->timed_launches = 1;
             c->timed_frames = frames;
@@ -1086,7 +1115,8 @@ int ldpc_amd_create(int32_t m, int32_t n, int64_t nnz, const int32_t* row_idx, c
     // every kernel object must have been compiled with the parameter structs this file uses
     if (bp_generic_params_bytes() != sizeof(BpParams) || bp_6_3_params_bytes() != sizeof(BpParams) ||
         bp_8_2_params_bytes() != sizeof(BpParams) || bp_lds_6_3_params_bytes() != sizeof(LdsParams) ||
-        bp_lds_8_2_params_bytes() != sizeof(LdsParams) || bp_lds_gen_params_bytes() != sizeof(LdsGenParams) ||
+        bp_lds_8_2_params_bytes() != sizeof(LdsParams) || bp_lds_8_4_params_bytes() != sizeof(LdsParams) ||
+        bp_lds_10_5_params_bytes() != sizeof(LdsParams) || bp_lds_gen_params_bytes() != sizeof(LdsGenParams) ||
         bp_rows_params_bytes() != sizeof(RowsParams) || bp_nodes_params_bytes() != sizeof(NodesParams))
         return fail(nullptr, LDPC_AMD_EHIP, "create: the library was linked from objects built against different headers");
     int ndev = 0;

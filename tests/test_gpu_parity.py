@@ -479,3 +479,66 @@ def test_page_locked_caller_buffers(pkg, c1, oracle, engine):
         got = c1["dec"].decode_bsc_batch(buf.array, 0.03, 50)
     for x, y in zip(got, want):
         assert (x == y).all()
+
+
+def _full_qc(pkg, z, mb, nb, seed):
+    """A draw of GenerateMatrix.generateQC without an empty block (about two in three at z = 108, 5 x 10): regular."""
+    for s in range(seed, seed + 200):
+        base, code = pkg.codes.random_qc(z, mb, nb, s)
+        if (np.asarray(base) >= 0).all():
+            return code
+    raise RuntimeError("no full base matrix")
+
+
+def test_resident_kernels_of_the_other_regular_shapes_and_tiled_lengths(pkg, oracle, engine):
+    """The frame-resident kernels also take the reference's (8,4) Gallager code (LDPC_GallagerLoopSimu.java:19-21)
+    and its full quasi-cyclic (10,5) codes (LDPC_QCIntStreamSimu.java:20-22), and regular codes whose length is
+    not a whole number of wavefronts are tiled as the next larger code with dummy nodes: equal to the
+    double-precision checker at the 99.99 % bar and bit for bit to the generic resident kernel and the sweeps."""
+    if engine != "resident":
+        pytest.skip("comparison runs once")
+    cases = (
+        ("gallager (8,4) n=1024", pkg.codes.gallager(1024, 8, 4, seed=2), 3.0, 0),
+        ("qc (10,5) z=108 n=1080, tiled as 1280", _full_qc(pkg, 108, 5, 10, 1), 2.5, 200),
+        ("(3,6) n=2040, tiled as 2048", pkg.codes.regular_ldpc(2040, 3, 6, seed=4), 1.6, 8),
+        ("gallager (8,2) n=1000, tiled as 1024", pkg.codes.gallager(1000, 8, 2, seed=5), 4.0, 24),
+        ("gallager (8,4) n=520, tiled as 1024", pkg.codes.gallager(520, 8, 4, seed=6), 3.0, 504),
+    )
+    F = 1200
+    for name, (m, n, rows, cols), ebn0, dummies in cases:
+        dec = pkg.Decoder(m, n, rows, cols)
+        g = oracle.Graph(m, n, rows, cols)
+        llr = oracle.gen_awgn_llr(m, n, ebn0, seed=31, first_frame=0, frames=F)
+        for early, L in ((True, 40), (False, 11)):
+            pkg.capi.set_default_options()
+            a = dec.decode_batch(llr, L, early)
+            assert dec.last_decode_kernel() == "bp_lds_kernel", name
+            want = g.decode_llr_batch(llr, L, early)
+            frac, diff = _agreement(a, want)
+            assert diff.size <= MAX_DIFFERING(F), (name, early, _itemise(a, want, diff))
+            assert 0 < (a[2] == 0).sum() and ((a[2] > 0).any() or early), name    # a mix of decoded and undecoded frames
+            for opt, kernel in (("resident_generic", "bp_lds_gen_kernel"), ("stream_rows", "rows_cn_kernel")):
+                pkg.capi.set_default_options(**ENGINE_OPTIONS[opt])
+                try:
+                    b = dec.decode_batch(llr, L, early)
+                    assert dec.last_decode_kernel() == kernel
+                finally:
+                    pkg.capi.set_default_options()
+                for x, y in zip(a, b):
+                    assert (x == y).all(), (name, early, kernel)
+        # the reference's own calling convention, and ragged batch sizes
+        e = 0.02 if n > 600 else 0.01
+        for Fr in (1, 63, 130):
+            r = oracle.gen_bsc(m, n, oracle.CH_BSC_INFO, e, seed=33, first_frame=7, frames=Fr)
+            a = dec.decode_bsc_batch(r, e, 50, oracle.LLR_PARITY_LN1E20, True)
+            assert dec.last_decode_kernel() == "bp_lds_kernel"
+            want = g.decode_llr_batch_f64(oracle.bsc_llr_batch(m, n, r, e, oracle.LLR_PARITY_LN1E20), 50, True)
+            frac, diff = _agreement(a, want)
+            assert diff.size == 0, (name, Fr, _itemise(a, want, diff))
+        # a leg with the accounting inside the kernel against the counting pass
+        dec.set_option("sim_fused", 1)
+        x = dec.simulate(oracle.CH_AWGN, ebn0, 5, 11, 700, 30, True)
+        dec.set_option("sim_fused", 0)
+        y = dec.simulate(oracle.CH_AWGN, ebn0, 5, 11, 700, 30, True)
+        assert (x == y).all() and x[0] == 700, (name, x[:12], y[:12])
+        dec.close()
