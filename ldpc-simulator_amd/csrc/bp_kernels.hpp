@@ -66,6 +66,15 @@ struct BpParams {
     int32_t* out_synd;       // [frames_total] or null
     int lds_maxd;            // rows of LDS staging per wave and array (0 = no LDS path)
     int bits_bytes;          // 1: a wave's share of a decision word is one or more whole bytes (8 variables), stored as bytes
+    // Leaves: a variable of degree 1 sends its check lambda in every iteration and takes no part in any other
+    // message, and what the check sends back only enters its own decision.  Where the decisions of an iteration
+    // are not needed (fixed iterations, all but the last) a sweep can leave the leaves alone: the check-node sweep
+    // does not store alpha on a leaf edge, so that the lambda the variable-node sweep of iteration 0 wrote there
+    // stays, and the variable-node sweep skips the leaf - 4 bytes of traffic per leaf edge and iteration instead
+    // of 20, the same bits at the end.  Only leaves whose edge is the last of a register-resident row are marked.
+    const uint8_t* leaf_row;  // [m] 1: the last edge of the check leads to a marked leaf; null = no leaves marked
+    const uint8_t* leaf_var;  // [n] 1: marked leaf
+    int leaf_skip;            // 1: this sweep leaves the marked leaves alone
 };
 
 // ---- vector access helpers: FPL consecutive floats / words per lane -------------------
@@ -352,7 +361,8 @@ __device__ __forceinline__ void cn_compute(float (&b)[D][FPL]) {
 // One check of compile-time degree D.  `row` points at this lane's slot of the check's first
 // edge row; FIRST reads beta = lambda + 0.0 through the column indices instead.
 template <int FPL, int D, int RULE, bool FIRST>
-__device__ __forceinline__ void cn_row(float* row, const float* lam, const int* cols, long long T, long long LT) {
+__device__ __forceinline__ void cn_row(float* row, const float* lam, const int* cols, long long T, long long LT,
+                                       bool skip_last = false) {
     float b[D][FPL];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
@@ -366,7 +376,8 @@ __device__ __forceinline__ void cn_row(float* row, const float* lam, const int* 
     }
     cn_compute<FPL, D, RULE>(b);
 #pragma unroll
-    for (int k = 0; k < D; ++k) stv<FPL>(row + (long long)k * T, b[k]);
+    for (int k = 0; k < D; ++k)
+        if (k + 1 < D || !skip_last) stv<FPL>(row + (long long)k * T, b[k]);  // skip_last: see BpParams::leaf_row
 }
 
 // Any degree up to the LDS capacity, one frame per lane: tanh values and exclusive prefix
@@ -539,7 +550,7 @@ __device__ __forceinline__ float vn_col_lds(float* msg, const float* lamrow, con
 #define LDPC_CASE_CN(D)                                                              \
     case D:                                                                          \
         if constexpr (D <= (FPL == 1 ? kRegDegCn : kRegDegFpl4))                     \
-            cn_row<FPL, D, RULE, FIRST>(row, lam, cols, T, LT);                          \
+            cn_row<FPL, D, RULE, FIRST>(row, lam, cols, T, LT, skip_last);               \
         else if constexpr (FPL == 1)                                                 \
             cn_row_lds<RULE, FIRST>(row, lam, cols, T, LT, d, lds, cap, lane);           \
         break;
@@ -553,7 +564,7 @@ __device__ __forceinline__ float vn_col_lds(float* msg, const float* lamrow, con
 
 template <int FPL, int RULE, bool FIRST>
 __device__ __forceinline__ void cn_dispatch(int d, float* row, const float* lam, const int* cols, long long T,
-                                            long long LT, float* lds, int cap, int lane) {
+                                            long long LT, float* lds, int cap, int lane, bool skip_last = false) {
     switch (d) {
         case 0: break;
         LDPC_CASE_CN(1) LDPC_CASE_CN(2) LDPC_CASE_CN(3) LDPC_CASE_CN(4)
@@ -614,7 +625,8 @@ __device__ __forceinline__ void cn_load_at(const BpParams& p, const float* msg, 
 }
 
 template <int FPL, int D, int RULE, bool FIRST>
-__device__ __forceinline__ void cn_finish_at(const BpParams& p, float* msg, long long e0, float (&b)[D][FPL]) {
+__device__ __forceinline__ void cn_finish_at(const BpParams& p, float* msg, long long e0, float (&b)[D][FPL],
+                                             bool skip_last = false) {
     if constexpr (FIRST) {
 #pragma unroll
         for (int k = 0; k < D; ++k)
@@ -623,7 +635,8 @@ __device__ __forceinline__ void cn_finish_at(const BpParams& p, float* msg, long
     }
     cn_compute<FPL, D, RULE>(b);
 #pragma unroll
-    for (int k = 0; k < D; ++k) stv<FPL>(msg + (e0 + k) * p.msg_row, b[k]);
+    for (int k = 0; k < D; ++k)
+        if (k + 1 < D || !skip_last) stv<FPL>(msg + (e0 + k) * p.msg_row, b[k]);
 }
 
 template <int FPL, int D, bool FIRST>
@@ -670,13 +683,14 @@ __device__ __forceinline__ int cn_run(const BpParams& p, float* msg, const float
             for (int g = 0; g < G; ++g) cn_load_at<FPL, D, FIRST>(p, msg, lam, (long long)e0 + g * D, buf[g]);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                cn_finish_at<FPL, D, RULE, FIRST>(p, msg, (long long)e0 + g * D, buf[g]);
+                cn_finish_at<FPL, D, RULE, FIRST>(p, msg, (long long)e0 + g * D, buf[g], p.leaf_skip && p.leaf_row[i + g]);
                 __builtin_amdgcn_sched_barrier(0);  // one row's temporaries at a time
             }
             return G;
         }
     }
-    cn_row<FPL, D, RULE, FIRST>(msg + (long long)e0 * p.msg_row, lam, p.edge_col + e0, p.msg_row, p.lam_row);
+    cn_row<FPL, D, RULE, FIRST>(msg + (long long)e0 * p.msg_row, lam, p.edge_col + e0, p.msg_row, p.lam_row,
+                                p.leaf_skip && p.leaf_row[i]);
     return 1;
 }
 
@@ -703,7 +717,7 @@ __device__ __forceinline__ void cn_rows_any(const BpParams& p, float* msg, const
             default: break;
         }
         cn_dispatch<FPL, RULE, FIRST>(d, msg + (long long)e0 * p.msg_row, lam, p.edge_col + e0, p.msg_row, p.lam_row, lds,
-                                      p.lds_maxd, lane);
+                                      p.lds_maxd, lane, p.leaf_skip && p.leaf_row[i]);
         ++i;
     }
 }
@@ -852,6 +866,11 @@ __device__ __forceinline__ void vn_cols_any(const BpParams& p, float* msg, const
     while (j < j1) {
         const int c0 = p.col_ptr[j];
         const int d = p.col_ptr[j + 1] - c0;
+        if (p.leaf_skip && p.leaf_var[j]) {  // its slot keeps lambda and nobody reads its decision (BpParams::leaf_row)
+            flush_decisions<FPL>(p, bits, j, acc);
+            ++j;
+            continue;
+        }
         switch (d) {
             LDPC_RUN_VN(1) LDPC_RUN_VN(2) LDPC_RUN_VN(3) LDPC_RUN_VN(4) LDPC_RUN_VN(5) LDPC_RUN_VN(6)
             LDPC_RUN_VN(7) LDPC_RUN_VN(8) LDPC_RUN_VN(9) LDPC_RUN_VN(10) LDPC_RUN_VN(11) LDPC_RUN_VN(12)

@@ -36,6 +36,9 @@ hipError_t run(const RowsLaunch& l, RowsParams p) {
     for (int it = 0; it < p.b.max_iters; ++it) {
         p.iter = it;
         const bool last = it + 1 == p.b.max_iters;
+        // fixed iterations: the sweeps of iterations 1 .. L - 2 leave the marked leaves alone (BpParams::leaf_row); the
+        // variable-node sweep of iteration 0 has written lambda to their slots, the last iteration decides them
+        p.b.leaf_skip = (p.b.leaf_row && !p.early && it >= 1 && it + 2 <= p.b.max_iters) ? 1 : 0;
         launch_cn<FPL, DC>(l, p, grid, block, it == 0);
         const int write_beta = (p.early || !last) ? 1 : 0;
         if (FPL == 1 && p.fused && it > 0)

@@ -30,6 +30,7 @@ struct Options {
     int nodes = -1;
     int sim_overlap = 1;
     int sim_fused = 1;
+    int rows_leaves = 1;
     int verbose = 0;
     int lds_wpe = 0, lds_fpw = 0, generic_lds_kb = 0, nodes_blocks = 0, fpl = 0, layout = 0, rows_waves = 0, wps = 0,
         nopipe = 0, rows_fused = -1, generic_threads = 0, lds_vpt = 0;
@@ -44,6 +45,7 @@ struct ldpc_amd_ctx {
     int max_dc = 0, max_dv = 0;
     int reg_dc = 0, reg_dv = 0;  // the common degree when every check / variable has it, else 0
     int cn_rule = LDPC_AMD_CN_SUMPRODUCT;
+    uint8_t* d_leaf = nullptr;  // leaf_row[m] | leaf_var[n] (BpParams), null when the code has no leaf to mark
     int* d_row_ptr = nullptr;
     int* d_edge_col = nullptr;
     int* d_col_ptr = nullptr;
@@ -900,6 +902,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     p.frames_total = frames; p.max_iters = max_iters;
     p.out_iters = d_iters; p.out_synd = d_synd;
     p.lds_maxd = lds_maxd;
+    if (c->d_leaf && c->opt.rows_leaves) { p.leaf_row = c->d_leaf; p.leaf_var = c->d_leaf + c->m; }  // used by the sweep launches only
     const bool pipelined = c->opt.nopipe == 0;  // A/B: per-row dispatch kernels
     int chunks = 1, rows_per_chunk = c->m, vars_per_chunk = (n + 31) / 32 * 32;
     bool fuse_syndrome = false;
@@ -1171,6 +1174,28 @@ int ldpc_amd_create(int32_t m, int32_t n, int64_t nnz, const int32_t* row_idx, c
         (c->E && (e = hipMemcpy(c->d_edge_col, c->h_edge_col.data(), (size_t)c->E * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) ||
         (c->E && (e = hipMemcpy(c->d_col_edge, c->h_col_edge.data(), (size_t)c->E * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess))
         return bail(LDPC_AMD_EHIP, std::string("create: hipMemcpy: ") + hipGetErrorString(e));
+    {
+        // leaves the sweeps may leave alone (BpParams::leaf_row): variables of degree 1 whose edge is the last of a
+        // check that every kernel keeps in registers
+        std::vector<uint8_t> leaf((size_t)m + (size_t)n, 0);
+        size_t marked = 0;
+        for (int i = 0; i < m; ++i) {
+            const int e0 = c->h_row_ptr[(size_t)i], e1 = c->h_row_ptr[(size_t)i + 1];
+            if (e1 - e0 < 2 || e1 - e0 > 16) continue;
+            const int j = c->h_edge_col[(size_t)e1 - 1];
+            if (c->h_col_ptr[(size_t)j + 1] - c->h_col_ptr[(size_t)j] != 1) continue;
+            leaf[(size_t)i] = 1;
+            leaf[(size_t)m + (size_t)j] = 1;
+            ++marked;
+        }
+        if (marked) {
+            if ((e = hipMalloc((void**)&c->d_leaf, leaf.size())) != hipSuccess)
+                return bail(LDPC_AMD_ENOMEM, std::string("create: hipMalloc: ") + hipGetErrorString(e));
+            if ((e = hipMemcpy(c->d_leaf, leaf.data(), leaf.size(), hipMemcpyHostToDevice)) != hipSuccess)
+                return bail(LDPC_AMD_EHIP, std::string("create: hipMemcpy: ") + hipGetErrorString(e));
+        }
+        if (c->opt.verbose) fprintf(stderr, "ldpc_amd: %zu leaves marked\n", marked);
+    }
     *out = c;
     return LDPC_AMD_OK;
 }
@@ -1183,7 +1208,7 @@ int ldpc_amd_destroy(ldpc_amd_ctx* c) {
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
         void* ptrs[] = {c->d_row_ptr, c->d_edge_col, c->d_col_ptr, c->d_col_edge, c->ws, c->d_res,
                         c->stage[0],  c->stage[1],   c->stage[2],  c->stage[3],   c->d_counters, c->d_gen,      c->stage_cw,
-                        c->stage[4],  c->stage[5],   c->stage[6],  c->stage[7],   c->d_genres};
+                        c->stage[4],  c->stage[5],   c->stage[6],  c->stage[7],   c->d_genres,   c->d_leaf};
         for (int i = 0; i < 2; ++i) {
             if (c->io_stream[i]) (void)hipStreamDestroy(c->io_stream[i]);
             if (c->io_decoded[i]) (void)hipEventDestroy(c->io_decoded[i]);
@@ -1255,6 +1280,7 @@ int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
         case LDPC_AMD_OPT_TUNE_WPS: if (!(value == 0 || value == 2 || value == 4)) break; o.wps = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_NOPIPE: if (!range(0, 1)) break; o.nopipe = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_ROWS_FUSED: if (!range(-1, 1)) break; o.rows_fused = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_ROWS_LEAVES: if (!range(0, 1)) break; o.rows_leaves = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_LDS_VPT: if (!(value == 0 || value == 8 || value == 16)) break; o.lds_vpt = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: if (!(value == 0 || (value >= 64 && value <= 512 && value % 64 == 0))) break; o.generic_threads = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: if (!range(0, 1)) break; o.test_nodes_oversize = v; return LDPC_AMD_OK;
@@ -1287,6 +1313,7 @@ int ldpc_amd_get_option(const ldpc_amd_ctx* c, int32_t key, int64_t* value) {
         case LDPC_AMD_OPT_TUNE_WPS: *value = o.wps; break;
         case LDPC_AMD_OPT_TUNE_NOPIPE: *value = o.nopipe; break;
         case LDPC_AMD_OPT_TUNE_ROWS_FUSED: *value = o.rows_fused; break;
+        case LDPC_AMD_OPT_TUNE_ROWS_LEAVES: *value = o.rows_leaves; break;
         case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: *value = o.generic_threads; break;
         case LDPC_AMD_OPT_TUNE_LDS_VPT: *value = o.lds_vpt; break;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: *value = o.test_nodes_oversize; break;
