@@ -542,3 +542,41 @@ def test_resident_kernels_of_the_other_regular_shapes_and_tiled_lengths(pkg, ora
         y = dec.simulate(oracle.CH_AWGN, ebn0, 5, 11, 700, 30, True)
         assert (x == y).all() and x[0] == 700, (name, x[:12], y[:12])
         dec.close()
+
+
+def test_sweeps_that_leave_the_leaves_alone_return_the_same_bits(pkg, oracle, engine):
+    """Fixed iterations on codes with variables of degree 1: iterations 1 .. L-2 of the sweeps skip them (no alpha
+    stored on their edge, no variable-node update).  Same bits as with every sweep touching them (option
+    rows_leaves = 0) and as the checker; L = 1, 2, 3 exercise the first / last iteration rules; a random
+    irregular code has leaves in the middle of rows (not marked) next to marked ones."""
+    if engine != "resident":
+        pytest.skip("comparison runs once")
+    rng = np.random.default_rng(8)
+    m, n = 150, 400
+    H = (rng.random((m, n)) < 0.02).astype(np.uint8)
+    H[:, :100] |= (rng.random((m, 100)) < 0.03).astype(np.uint8)          # a denser core
+    H[np.arange(m), rng.integers(0, 100, m)] = 1                            # no empty row
+    tail = np.arange(250, 400)                                              # 150 leaves: column 250 + i in row perm(i) only
+    H[:, tail] = 0
+    H[rng.permutation(m), tail] = 1
+    rows, cols = np.nonzero(H)
+    codes = [("random irregular with leaves", (m, n, rows.astype(np.int32), cols.astype(np.int32)), 3.0),
+             ("NR-BG1-shaped Z=8", pkg.codes.nr_bg1_shaped(z=8, seed=5)[1], 1.5)]
+    F = 700
+    for name, (m, n, rows, cols), ebn0 in codes:
+        dec = pkg.Decoder(m, n, rows, cols)
+        g = oracle.Graph(m, n, rows, cols)
+        llr = oracle.gen_awgn_llr(m, n, ebn0, seed=41, first_frame=0, frames=F)
+        dec.set_option("engine", "stream")
+        for L in (1, 2, 3, 12):
+            dec.set_option("rows_leaves", 1)
+            a = dec.decode_batch(llr, L, False)
+            assert dec.last_decode_kernel() == "rows_cn_kernel"
+            dec.set_option("rows_leaves", 0)
+            b = dec.decode_batch(llr, L, False)
+            for x, y in zip(a, b):
+                assert (x == y).all(), (name, L)
+            want = g.decode_llr_batch(llr, L, False)
+            frac, diff = _agreement(a, want)
+            assert diff.size <= MAX_DIFFERING(F), (name, L, _itemise(a, want, diff))
+        dec.close()
