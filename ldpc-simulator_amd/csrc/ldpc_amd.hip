@@ -636,9 +636,10 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
                      : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
             l.early = early; l.threads = nt; l.vpt = vpt; l.lds_bytes = lds_bytes; l.stream = s;
-            // measured: three workgroups per CU (80 registers) pay off for the (6,3) kernels; the (8,2)
-            // kernels lose more to register spills than they gain in occupancy
-            l.wpe = dcr == 6 ? 6 : 4;
+            // measured: 80 registers (six wavefronts per SIMD) pay off for the (6,3) kernels and the (10,5) kernels
+            // (QC z = 108: 49.0 -> 45.0 ms per 262,144 frames); the (8,2) and (8,4) kernels lose more to register
+            // spills than they gain in occupancy
+            l.wpe = (dcr == 6 || dcr == 10) ? 6 : 4;
             if (c->opt.lds_wpe) l.wpe = c->opt.lds_wpe;
             // with early termination a workgroup takes several frames in turn, once there are enough of
             // them to keep every CU supplied with workgroups that finish at different times

@@ -20,6 +20,8 @@ def full_qc(z, mb, nb, seed):
 def run(name, code, F, ebn0):
     m, n, rows, cols = code
     dec = L.Decoder(m, n, rows, cols)
+    if os.environ.get("PERF_LDS_WPE"):
+        dec.set_option("lds_wpe", int(os.environ["PERF_LDS_WPE"]))   # measurements: register budget of the resident kernels
     d_llr = torch.empty((F, n), dtype=torch.float32, device="cuda")
     dec.gen_awgn_llr_dev(ebn0, 3, 0, F, d_llr.data_ptr())
     out = {}
