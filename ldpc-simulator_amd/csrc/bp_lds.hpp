@@ -77,7 +77,8 @@ __device__ __forceinline__ void lds_store(uint32_t a, float v) { *(lds_float*)(u
 struct LdsYes { static constexpr bool value = true; };
 struct LdsNo { static constexpr bool value = false; };
 
-// VPT variables and CPT = VPT * DV / DC (even) checks per thread, exactly: n = VPT * blockDim.x, m = CPT * blockDim.x.
+// VPT variables and CPT = VPT * DV / DC (even) checks per thread, exactly: the tiling has VPT * blockDim.x variables
+// and CPT * blockDim.x checks (p.m); a shorter code fills the rest with dummy nodes (LdsParams::n).
 // WPE = wavefronts per SIMD the register budget is set for.  VPT = 8: 6 (80 registers, three 8-wave workgroups
 // per CU) or 4 (128 registers, two).  VPT = 16: 3 (168 registers, three 4-wave workgroups per CU at n = 4096).
 // COUNT: error accounting in place of the outputs (LdsParams::counters; LDPC_GallagerIntStreamSimu.java:136-183).
@@ -124,9 +125,7 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
     if constexpr (COUNT)
         for (int i = t; i < nc; i += nt) wcnt[i] = 0ull;
     for (long long frame = blockIdx.x; frame < p.frames; frame += gridDim.x) {
-    if (t == 0) {
-        *red = 0;
-    }
+    if (t == 0) *red = 0;
     // The syndrome is kept as one bit per check.  With early termination it is maintained every iteration
     // by toggling the checks of the variables whose decision changed since the previous one (few, after
     // the first iterations); at fixed iterations it is formed once at the end, from the variables decided
@@ -443,7 +442,7 @@ struct LdsLaunch {
     int frames_per_wg;  // frames one workgroup decodes in turn (>= 1; early termination only)
     int wpe;  // 4 or 6, see bp_lds_kernel
     int vpt;  // variables per thread: kLdsVpt or kLdsVptWide
-    bool count;  // error accounting inside the kernel (default check-node rule, 8 variables per thread)
+    bool count;  // error accounting inside the kernel (default check-node rule, at most 8 variables per thread)
     int threads;
     size_t lds_bytes;
     hipStream_t stream;
