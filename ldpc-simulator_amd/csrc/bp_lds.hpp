@@ -74,6 +74,7 @@ __device__ __forceinline__ uint32_t lds_address(const void* generic) {
 __device__ __forceinline__ float lds_load(uint32_t a) { return *(const lds_float*)(uintptr_t)a; }
 __device__ __forceinline__ void lds_store(uint32_t a, float v) { *(lds_float*)(uintptr_t)a = v; }
 
+template <int V> struct LdsInt { static constexpr int value = V; };
 struct LdsYes { static constexpr bool value = true; };
 struct LdsNo { static constexpr bool value = false; };
 
@@ -133,7 +134,6 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
     uint32_t* par = reinterpret_cast<uint32_t*>(red + 4);   // [m / 32]
     const int mw = p.m >> 5;
     for (int w = t; w < mw; w += nt) par[w] = 0u;
-    uint32_t mydec = 0u;  // bit v: the current decision of this thread's variable v
 
     // Channel LLRs of this thread's own variables (LogDecoder.java:49-54 for a hard received word); they stay
     // in registers for the whole decode.  The eight table reads go out together and so do the eight gathers
@@ -219,32 +219,52 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
         }
     __syncthreads();
 
-    // toggles the syndrome bits of the checks of those of this thread's variables whose bit is set in
-    // `which` (static indices into off[][]: a run-time index would move the array to scratch memory)
-    auto toggle_checks = [&](uint32_t which) {
+    // Decisions are kept as lane masks, one 64-bit scalar per variable of the thread (bit l: the decision of lane l's
+    // variable v): a sign test writes such a mask directly, "did any lane change" is scalar arithmetic, and the
+    // lanes that have to act are selected by the mask itself.  (As bits of a vector register, eight compares,
+    // selects and merges per iteration and eight more tests to take them apart cost 9 % of an iteration.)
+    // toggle_var(v, lanes): toggles the syndrome bits of the checks of variable v in the lanes of the mask (static
+    // indices into off[][]: a run-time index would move the array to scratch memory)
+    auto toggle_var = [&](auto vc, unsigned long long lanes) {
+        constexpr int v = decltype(vc)::value;
+        if (lanes == 0ull) return;
+        if (__builtin_amdgcn_inverse_ballot_w64(lanes)) {
 #pragma unroll
-        for (int v = 0; v < kLdsVpt; ++v) {
-            if ((which >> v) & 1u) {
-#pragma unroll
-                for (int k = 0; k < DV; ++k) {
-                    // slot -> syndrome bit: 2 * (pair row) + (which check of the pair); any fixed
-                    // one-to-one numbering of the checks serves
-                    uint32_t o = off[v][k];
-                    asm volatile("" : "+v"(o));  // formed here, when needed: 24 more loop invariants do not fit
-                    const uint32_t slot = (o - lds_base) >> 2;
-                    const uint32_t b = 2u * (slot / (uint32_t)lds_pair_stride(DC)) + (slot & 1u);
-                    atomicXor(&par[b >> 5], 1u << (b & 31u));
-                }
+            for (int k = 0; k < DV; ++k) {
+                // slot -> syndrome bit: 2 * (pair row) + (which check of the pair); any fixed
+                // one-to-one numbering of the checks serves
+                uint32_t o = off[v][k];
+                asm volatile("" : "+v"(o));  // formed here, when needed: 24 more loop invariants do not fit
+                const uint32_t slot = (o - lds_base) >> 2;
+                const uint32_t b = 2u * (slot / (uint32_t)lds_pair_stride(DC)) + (slot & 1u);
+                atomicXor(&par[b >> 5], 1u << (b & 31u));
             }
         }
     };
+    auto toggle_all = [&](const unsigned long long (&lanes)[kLdsVpt]) {
+        toggle_var(LdsInt<0>{}, lanes[0]); toggle_var(LdsInt<1>{}, lanes[1]);
+        toggle_var(LdsInt<2>{}, lanes[2]); toggle_var(LdsInt<3>{}, lanes[3]);
+        if constexpr (kLdsVpt > 4) {
+            toggle_var(LdsInt<4>{}, lanes[4]); toggle_var(LdsInt<5>{}, lanes[5]);
+            toggle_var(LdsInt<6>{}, lanes[6]); toggle_var(LdsInt<7>{}, lanes[7]);
+        }
+        if constexpr (kLdsVpt > 8) {
+            toggle_var(LdsInt<8>{}, lanes[8]); toggle_var(LdsInt<9>{}, lanes[9]);
+            toggle_var(LdsInt<10>{}, lanes[10]); toggle_var(LdsInt<11>{}, lanes[11]);
+            toggle_var(LdsInt<12>{}, lanes[12]); toggle_var(LdsInt<13>{}, lanes[13]);
+            toggle_var(LdsInt<14>{}, lanes[14]); toggle_var(LdsInt<15>{}, lanes[15]);
+        }
+    };
+    unsigned long long decm[kLdsVpt];  // the current decisions
+#pragma unroll
+    for (int v = 0; v < kLdsVpt; ++v) decm[v] = 0ull;
 
     int iters = p.max_iters, synd = 0;
     bool converged = false;
     // One iteration up to the barrier that ends its variable-node phase.  DECIDE: also form the decisions; at
     // fixed iterations only the last iteration's are ever read (LogDecoder.java:98-105 forms them every time,
     // LogDecoder.java:122 returns the last), so the others skip the posterior sum and the sign tests.
-    auto iteration = [&](auto decide, bool write_beta) -> uint32_t {
+    auto iteration = [&](auto decide, bool write_beta, unsigned long long (&newm)[kLdsVpt]) {
         constexpr bool DECIDE = decltype(decide)::value;
         // check nodes: beta -> alpha in place, two checks per step in the halves of packed registers
 #pragma unroll
@@ -275,7 +295,6 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
         for (int v = 0; v < kLdsVpt; v += 2)
 #pragma unroll
             for (int k = 0; k < DV; ++k) va[v / 2][k] = v2f{lds_load(off[v][k]), lds_load(off[v + 1][k])};
-        uint32_t newdec = 0u;
 #pragma unroll
         for (int v = 0; v < kLdsVpt; v += 2) {
             v2f g;
@@ -288,16 +307,23 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
                 }
             }
             // "(gamma[j] < 0) ? 1 : 0", :104
-            if constexpr (DECIDE) newdec |= (g.x < 0.0f ? 1u : 0u) << v | (g.y < 0.0f ? 1u : 0u) << (v + 1);
+            if constexpr (DECIDE) {
+                newm[v] = __ballot(g.x < 0.0f);
+                newm[v + 1] = __ballot(g.y < 0.0f);
+            }
         }
-        return newdec;
     };
     if constexpr (EARLY) {
         for (int it = 0; it < p.max_iters; ++it) {
-            const uint32_t newdec = iteration(LdsYes{}, true);
-            const uint32_t changed = newdec ^ mydec;
-            mydec = newdec;
-            if (changed) toggle_checks(changed);  // rare after the first iterations
+            unsigned long long newm[kLdsVpt];
+            iteration(LdsYes{}, true, newm);
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; ++v) {
+                const unsigned long long now = newm[v];
+                newm[v] ^= decm[v];     // the lanes whose decision changed: few after the first iterations
+                decm[v] = now;
+            }
+            toggle_all(newm);
             __syncthreads();
             // "sumSyndro == 0" (LogDecoder.java:108-119): no bit set in any word.  Every wave scans all the
             // words for itself, so all reach the same verdict without a reduction or a second barrier (the
@@ -316,31 +342,28 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
         }
     } else {
         for (int it = 0; it + 1 < p.max_iters; ++it) {
-            iteration(LdsNo{}, true);
+            iteration(LdsNo{}, true, decm);
             __syncthreads();
         }
-        mydec = iteration(LdsYes{}, false);
+        iteration(LdsYes{}, false, decm);
         __syncthreads();
     }
     // decisions -> packed words by VN position: position t + v*nt of lane 0 of a wave is a multiple of 64, so its
     // word is (t >> 5) + v * (nt >> 5)
     if constexpr (!COUNT) {
-        unsigned long long mask[kLdsVpt];
-#pragma unroll
-        for (int v = 0; v < kLdsVpt; ++v) mask[v] = __ballot((mydec >> v) & 1u);
         if ((tt & 63) == 0) {
             uint32_t* b0 = bits + (tt >> 5);
             const int step = nt >> 5;
 #pragma unroll
             for (int v = 0; v < kLdsVpt; ++v) {
-                b0[v * step] = (uint32_t)mask[v];
-                b0[v * step + 1] = (uint32_t)(mask[v] >> 32);
+                b0[v * step] = (uint32_t)decm[v];
+                b0[v * step + 1] = (uint32_t)(decm[v] >> 32);
             }
         }
     }
     __syncthreads();
     if constexpr (!EARLY) {  // "sumSyndro" of the last decisions (LogDecoder.java:108-116)
-        toggle_checks(mydec);
+        toggle_all(decm);
         __syncthreads();
     }
     if (!converged) {  // weight of the syndrome
@@ -358,6 +381,9 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
         // differ from the transmitted word at information / parity positions, channel errors at information
         // positions, wrong decisions where the channel had made none.  Each at most 8 per thread and n per
         // frame: two of them share a word.
+        uint32_t mydec = 0u;  // this thread's decisions, bit v = variable v
+#pragma unroll
+        for (int v = 0; v < kLdsVpt; ++v) mydec |= __builtin_amdgcn_inverse_ballot_w64(decm[v]) ? (1u << v) : 0u;
         const uint32_t sent = side & 0xffu;
         const uint32_t chan = ((side >> 8) & 0xffu) ^ sent, info = side >> 16;
         const uint32_t err = (mydec ^ sent) & 0xffu;
