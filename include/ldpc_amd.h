@@ -148,6 +148,8 @@ int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
                                                of the next iteration (1), in launches of its own (0), -1 = by batch size */
 #define LDPC_AMD_OPT_TUNE_ROWS_LEAVES 112    /* sweeps at fixed iterations: 1 (default) = iterations 1 .. L-2 leave variables of
                                                 degree 1 alone (same results, less traffic); 0 = every sweep touches them */
+#define LDPC_AMD_OPT_TUNE_SIM_CHUNK_MB 113   /* ldpc_amd_simulate: MiB of received and decoded words per chunk of a leg (default 2048;
+                                                a leg holds two such sets when its chunks overlap) */
 #define LDPC_AMD_OPT_TEST_NODES_OVERSIZE 190 /* tests: ask for a cooperative grid the runtime must refuse */
 /* read-only */
 #define LDPC_AMD_OPT_NODES_REFUSALS 200      /* cooperative launches the runtime refused on this context */

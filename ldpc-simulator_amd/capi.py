@@ -26,11 +26,11 @@ CNT_FIXED = 16
 OPT = {
     "engine": 1, "stream_kernel": 2, "nodes": 3, "sim_overlap": 4, "verbose": 5, "sim_fused": 6,
     "lds_wpe": 100, "lds_fpw": 101, "generic_lds_kb": 102, "nodes_blocks": 103, "fpl": 104, "layout": 105,
-    "rows_waves": 106, "wps": 107, "nopipe": 108, "rows_fused": 109, "generic_threads": 110, "lds_vpt": 111, "rows_leaves": 112, "test_nodes_oversize": 190,
+    "rows_waves": 106, "wps": 107, "nopipe": 108, "rows_fused": 109, "generic_threads": 110, "lds_vpt": 111, "rows_leaves": 112, "sim_chunk_mb": 113, "test_nodes_oversize": 190,
     "nodes_refusals": 200, "nodes_last_hip_error": 201, "noalloc_max_frames": 202,
 }
 OPT_READ_ONLY = ("nodes_refusals", "nodes_last_hip_error", "noalloc_max_frames")
-OPT_LIBRARY_DEFAULT = {"nodes": -1, "sim_overlap": 1, "sim_fused": 1, "rows_leaves": 1}   # every other option defaults to 0
+OPT_LIBRARY_DEFAULT = {"nodes": -1, "sim_overlap": 1, "sim_fused": 1, "rows_leaves": 1, "sim_chunk_mb": 2048}   # every other option defaults to 0
 ENGINE_AUTO, ENGINE_GENERIC, ENGINE_STREAM = 0, 1, 2
 ENGINES = {"auto": ENGINE_AUTO, "generic": ENGINE_GENERIC, "stream": ENGINE_STREAM}
 

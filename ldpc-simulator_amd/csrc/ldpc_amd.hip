@@ -31,6 +31,7 @@ struct Options {
     int sim_overlap = 1;
     int sim_fused = 1;
     int rows_leaves = 1;
+    int sim_chunk_mb = 2048;
     int verbose = 0;
     int lds_wpe = 0, lds_fpw = 0, generic_lds_kb = 0, nodes_blocks = 0, fpl = 0, layout = 0, rows_waves = 0, wps = 0,
         nopipe = 0, rows_fused = -1, generic_threads = 0, lds_vpt = 0;
@@ -1282,6 +1283,7 @@ int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
         case LDPC_AMD_OPT_TUNE_NOPIPE: if (!range(0, 1)) break; o.nopipe = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_ROWS_FUSED: if (!range(-1, 1)) break; o.rows_fused = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_ROWS_LEAVES: if (!range(0, 1)) break; o.rows_leaves = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_SIM_CHUNK_MB: if (!range(16, 65536)) break; o.sim_chunk_mb = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_LDS_VPT: if (!(value == 0 || value == 8 || value == 16)) break; o.lds_vpt = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: if (!(value == 0 || (value >= 64 && value <= 512 && value % 64 == 0))) break; o.generic_threads = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: if (!range(0, 1)) break; o.test_nodes_oversize = v; return LDPC_AMD_OK;
@@ -1315,6 +1317,7 @@ int ldpc_amd_get_option(const ldpc_amd_ctx* c, int32_t key, int64_t* value) {
         case LDPC_AMD_OPT_TUNE_NOPIPE: *value = o.nopipe; break;
         case LDPC_AMD_OPT_TUNE_ROWS_FUSED: *value = o.rows_fused; break;
         case LDPC_AMD_OPT_TUNE_ROWS_LEAVES: *value = o.rows_leaves; break;
+        case LDPC_AMD_OPT_TUNE_SIM_CHUNK_MB: *value = o.sim_chunk_mb; break;
         case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: *value = o.generic_threads; break;
         case LDPC_AMD_OPT_TUNE_LDS_VPT: *value = o.lds_vpt; break;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: *value = o.test_nodes_oversize; break;
@@ -1520,7 +1523,7 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
         if (int rc = bsc_magnitudes(c, param, mode, &l0, &l1)) return rc;
     }
     const size_t in_elem = awgn ? sizeof(float) : 1;
-    long long chunk = (long long)((2048ull << 20) / (n * (in_elem + 1) + 8));
+    long long chunk = (long long)(((unsigned long long)c->opt.sim_chunk_mb << 20) / (n * (in_elem + 1) + 8));
     chunk = std::max<long long>(256, std::min<long long>(chunk, 1ll << 20));
     chunk = std::min<long long>(chunk, std::max<long long>(frames, 1));
     // Chunks alternate between two sets of buffers on two streams: the channel generation of chunk i + 1

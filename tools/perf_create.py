@@ -1,5 +1,7 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""Time of ldpc_amd_create and of the first decode (tables of the engine are built then) for the reference's codes."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ldpc_simulator_amd as L
 import oracle.oracle_capi as oc

@@ -17,6 +17,8 @@ eh, eg = L.encoder.systematic_pair(L.check_matrix_io.to_dense(m, n, rows, cols))
 r2, c2 = np.nonzero(eh)
 dec = L.Decoder(m, n, r2.astype(np.int32), c2.astype(np.int32))
 dec.set_generator(eg)
+if os.environ.get("PERF_SIM_CHUNK_MB"):
+    dec.set_option("sim_chunk_mb", int(os.environ["PERF_SIM_CHUNK_MB"]))   # measurements: frames per chunk of a leg
 dec.simulate(L.capi.CH_AWGN, 4.0, 1, 0, 1 << 17, 50, True)  # warm-up
 print("frames per leg %d; M frames/s, best of 3" % frames)
 for ebn0 in points:
