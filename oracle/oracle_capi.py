@@ -86,7 +86,7 @@ class Graph:
         self.E = int(lib().oracle_graph_edges(h))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:   # at interpreter exit the module globals may be gone already
             lib().oracle_graph_destroy(self._h)
             self._h = None
 
