@@ -12,10 +12,21 @@ import ldpc_simulator_amd as L
 
 def random_code(rng):
     kind = rng.integers(0, 5)
-    if kind == 4:  # the shapes the specialised frame-resident kernels take
-        if rng.random() < 0.5:
-            return L.codes.regular_ldpc(512 * int(rng.integers(1, 9)), 3, 6, int(rng.integers(1, 1000)))
-        return L.codes.gallager(512 * int(rng.integers(1, 9)), 8, 2, int(rng.integers(1, 1000)))
+    if kind == 4:  # the shapes the specialised frame-resident kernels take, whole wavefronts or tiled as a larger code
+        shape = int(rng.integers(0, 6))
+        s = int(rng.integers(1, 1000))
+        if shape == 0:
+            return L.codes.regular_ldpc(512 * int(rng.integers(1, 9)), 3, 6, s)
+        if shape == 1:
+            return L.codes.gallager(512 * int(rng.integers(1, 9)), 8, 2, s)
+        if shape == 2:
+            return L.codes.gallager(8 * int(rng.integers(4, 300)), 8, 2 if rng.random() < 0.5 else 4, s)
+        if shape == 3:
+            return L.codes.regular_ldpc(12 * int(rng.integers(8, 340)), 3, 6, s)
+        if shape == 4:
+            return L.codes.regular_ldpc(20 * int(rng.integers(4, 200)), 5, 10, s)
+        z = int(rng.integers(8, 128))
+        return L.codes.qc_expand(rng.integers(0, z, (5, 10)), z)   # a quasi-cyclic (10,5) code without empty blocks
     if kind == 0:  # regular (dv, dc)
         dv, dc = [(3, 6), (2, 8), (3, 4), (4, 8), (2, 4)][rng.integers(0, 5)]
         n = int(rng.integers(2, 40)) * dc * (1 if rng.random() < 0.5 else 8)
@@ -75,6 +86,7 @@ def fuzz(cases, seed):
             call = lambda: dec.decode_batch(llr, iters, early)
         ref, _ = run(dec, call, {"engine": "stream", "stream_kernel": 0})
         for name, env in (("default", {}), ("generic", {"engine": "generic"}),
+                          ("sweeps, leaves touched", {"engine": "stream", "stream_kernel": 0, "rows_leaves": 0}),
                           ("one-launch", {"engine": "stream", "stream_kernel": 1}),
                           ("nodes", {"generic_lds_kb": -1, "engine": "generic", "nodes": 1})):
             out, kernel = run(dec, call, env)
