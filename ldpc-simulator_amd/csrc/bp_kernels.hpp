@@ -291,8 +291,9 @@ __device__ __forceinline__ void cn_complement(V (&b)[D]) {
     V sQ = vsplat<V>(0.0f);
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
-        // for the last member the suffix is empty: fma(0, 1 - pq, pq) = pq exactly (pq lies in [0, 1] or is NaN)
-        const V mag = atanh2_complement<V>((k == D - 1) ? pq[k] : vfma(sQ, one - pq[k], pq[k]));
+        // for the last member the suffix is empty: fma(0, 1 - pq, pq) = pq exactly (pq lies in [0, 1] or is NaN); for
+        // the first the prefix is: fma(sQ, 1 - 0, 0) = sQ exactly (sQ is never -0)
+        const V mag = atanh2_complement<V>((k == D - 1) ? pq[k] : (k == 0) ? sQ : vfma(sQ, one - pq[k], pq[k]));
         b[k] = vflip(mag, all ^ sg[k]);
         sQ = (k == D - 1) ? q[k] : vfma(q[k], one - sQ, sQ);
     }
