@@ -143,7 +143,7 @@ int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
 #define LDPC_AMD_OPT_TUNE_WPS 107            /* one-launch streaming kernel: wavefronts per SIMD (2 or 4) */
 #define LDPC_AMD_OPT_TUNE_NOPIPE 108         /* one-launch streaming kernel: 1 = no software pipelining */
 #define LDPC_AMD_OPT_TUNE_GENERIC_THREADS 110 /* generic frame-resident kernel: threads per frame (multiple of 64, 64..512), 0 = by code size */
-#define LDPC_AMD_OPT_TUNE_LDS_VPT 111         /* frame-resident (6,3) kernels: variables per thread (8 or 16) */
+#define LDPC_AMD_OPT_TUNE_LDS_VPT 111         /* frame-resident (6,3) kernels: variables per thread (8, 12 or 16; 0 = by code length) */
 #define LDPC_AMD_OPT_TUNE_ROWS_FUSED 109     /* sweeps with early termination: syndrome inside the check-node launch
                                                of the next iteration (1), in launches of its own (0), -1 = by batch size */
 #define LDPC_AMD_OPT_TUNE_ROWS_LEAVES 112    /* sweeps at fixed iterations: 1 (default) = iterations 1 .. L-2 leave variables of

@@ -23,6 +23,7 @@ namespace ldpc {
 
 constexpr int kLdsVpt = 8;   // variables per thread; threads per frame = n / 8, checks per thread = 8 m / n
 constexpr int kLdsVptWide = 16;  // the second tiling: half as many threads per frame, each with twice the nodes
+constexpr int kLdsVptMid = 12;   // a third one for the (6,3) kernels: n = 3072 in 4 wavefronts instead of 6 (or 1536 in 2 for 3)
 
 struct LdsParams {
     int m, n, nw;          // n: the caller's code length (stride of its frames); m, nw: checks and decision words of the
@@ -82,6 +83,7 @@ struct LdsNo { static constexpr bool value = false; };
 // and CPT * blockDim.x checks (p.m); a shorter code fills the rest with dummy nodes (LdsParams::n).
 // WPE = wavefronts per SIMD the register budget is set for.  VPT = 8: 6 (80 registers, three 8-wave workgroups
 // per CU) or 4 (128 registers, two).  VPT = 16: 3 (168 registers, three 4-wave workgroups per CU at n = 4096).
+// VPT = 12: 4 (103 registers).
 // COUNT: error accounting in place of the outputs (LdsParams::counters; LDPC_GallagerIntStreamSimu.java:136-183).
 template <int DC, int DV, int RULE, bool EARLY, int VPT, int WPE, bool COUNT = false>
 __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
@@ -251,6 +253,8 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
         if constexpr (kLdsVpt > 8) {
             toggle_var(LdsInt<8>{}, lanes[8]); toggle_var(LdsInt<9>{}, lanes[9]);
             toggle_var(LdsInt<10>{}, lanes[10]); toggle_var(LdsInt<11>{}, lanes[11]);
+        }
+        if constexpr (kLdsVpt > 12) {
             toggle_var(LdsInt<12>{}, lanes[12]); toggle_var(LdsInt<13>{}, lanes[13]);
             toggle_var(LdsInt<14>{}, lanes[14]); toggle_var(LdsInt<15>{}, lanes[15]);
         }
@@ -490,6 +494,7 @@ inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
 #define LDPC_LDS(R, E)                                                                                       \
     do {                                                                                                     \
         if constexpr (VPT == kLdsVptWide) LDPC_LDS2(R, E, 3);                                                \
+        else if constexpr (VPT == kLdsVptMid) LDPC_LDS2(R, E, 4);                                            \
         else if (l.wpe >= 6) LDPC_LDS2(R, E, 6); else LDPC_LDS2(R, E, 4);                                    \
     } while (0)
     if (l.count) {

@@ -503,6 +503,8 @@ def test_resident_kernels_of_the_other_regular_shapes_and_tiled_lengths(pkg, ora
         ("(3,6) n=2040, tiled as 2048", pkg.codes.regular_ldpc(2040, 3, 6, seed=4), 1.6, 8),
         ("gallager (8,2) n=1000, tiled as 1024", pkg.codes.gallager(1000, 8, 2, seed=5), 4.0, 24),
         ("gallager (8,4) n=520, tiled as 1024", pkg.codes.gallager(520, 8, 4, seed=6), 3.0, 504),
+        ("(3,6) n=3072, 12 variables per thread", pkg.codes.regular_ldpc(3072, 3, 6, seed=7), 1.6, 0),
+        ("(3,6) n=2256, 12 variables per thread, tiled as 2304", pkg.codes.regular_ldpc(2256, 3, 6, seed=8), 1.6, 48),
     )
     F = 1200
     for name, (m, n, rows, cols), ebn0, dummies in cases:
@@ -533,8 +535,15 @@ def test_resident_kernels_of_the_other_regular_shapes_and_tiled_lengths(pkg, ora
             a = dec.decode_bsc_batch(r, e, 50, oracle.LLR_PARITY_LN1E20, True)
             assert dec.last_decode_kernel() == "bp_lds_kernel"
             want = g.decode_llr_batch_f64(oracle.bsc_llr_batch(m, n, r, e, oracle.LLR_PARITY_LN1E20), 50, True)
+            # The words must be equal (the 99.99 % bar).  On the (3,6) codes a hard received word leaves posteriors
+            # that are exactly zero in exact arithmetic after the first iteration (a flipped bit with checks whose
+            # other members are one information bit and four error-free parity bits, and two checks of equal and
+            # opposite messages: -l0 + a + l0 - a); rounding decides their sign, so fp32 and double may stop an
+            # iteration apart with the same word - every engine alike.  Up to 5 % of such frames are let through.
+            _, hdiff = _hard_agreement(a, want)
+            assert hdiff.size == 0, (name, Fr, _itemise(a, want, hdiff))
             frac, diff = _agreement(a, want)
-            assert diff.size == 0, (name, Fr, _itemise(a, want, diff))
+            assert diff.size <= (max(1, Fr // 20) if name.startswith("(3,6)") else 0), (name, Fr, _itemise(a, want, diff))
         # a leg with the accounting inside the kernel against the counting pass
         dec.set_option("sim_fused", 1)
         x = dec.simulate(oracle.CH_AWGN, ebn0, 5, 11, 700, 30, True)
