@@ -55,6 +55,110 @@ def resident_ceilings():
     return valu, lds
 
 
+def transcendental_ceiling():
+    """The part of the VALU ceiling that does not depend on how this library arranges the rest of the rule: any
+    evaluation of 2 atanh(prod tanh(beta/2)) in LLR form issues at least 4 transcendental instructions per
+    edge-iteration on this instruction set (an exponential and a reciprocal to get from beta to a factor, a
+    reciprocal and a logarithm to get back), each 8.1 SIMD cycles per wave64; the other vector work priced at zero."""
+    return SIMDS * CLOCK_HZ * 64 / (4 * TRANS_CYCLES)
+
+
+def resident_roofline(edge_iters_per_s):
+    valu_peak, lds_peak = resident_ceilings()
+    trans_peak = transcendental_ceiling()
+    return {
+        "bound": "valu_issue", "achieved": edge_iters_per_s / 1e12, "peak": valu_peak / 1e12, "unit": "Tedge-iterations/s",
+        "frac": edge_iters_per_s / valu_peak,
+        "peak_definition": "1024 SIMDs x 2.4 GHz x 64 lanes / %.1f issue cycles per 64 edge-iterations "
+                           "(4 transcendentals x %.1f cycles + 12 fp32 operations x %.3f cycles, the issue rates "
+                           "measured by tools/valu_rates.hip); the 12 operations are this library's own recipe"
+                           % (VALU_FLOOR_CYCLES_PER_64_EDGE_ITERS, TRANS_CYCLES, FP32_ELEMENT_CYCLES),
+        "transcendental_floor": {"peak": trans_peak / 1e12, "unit": "Tedge-iterations/s", "frac": edge_iters_per_s / trans_peak,
+                                 "peak_definition": "1024 SIMDs x 2.4 GHz x 64 lanes / (4 transcendentals x %.1f cycles): "
+                                                    "the formulation-independent part of the ceiling, all other vector "
+                                                    "work priced at zero" % TRANS_CYCLES},
+        "lds_ceiling": {"peak": lds_peak / 1e12, "unit": "Tedge-iterations/s", "frac": edge_iters_per_s / lds_peak,
+                        "peak_definition": "256 CUs x 2.4 GHz / %.3f LDS cycles per edge-iteration (b128 read and "
+                                           "write on the check side, b32 read and write on the variable side)"
+                                           % LDS_FLOOR_CYCLES_PER_EDGE_ITER},
+    }
+
+
+def other_configs(L, torch, stream):
+    """The other BASELINE configurations, one short measurement each (N = 1 only, after the timed region, not part
+    of `value`): C1 the reference's own code (LDPC_GallagerIntStreamSimu.java:20-24) at 1,048,576 frames x 50 fixed
+    iterations; C4 the NR-BG1-sized Z = 384 code, 65,536 frames x 50 fixed iterations; C5 the n = 64,800 code with
+    1 and 64 frames and early termination.  Each decode runs twice, the second is reported: wall time between
+    synchronisations and the message-passing launches between HIP events."""
+    out = {}
+
+    def run(dec, ebn0, F, iters, early, seed):
+        n = dec.n
+        d_llr = torch.empty((F, n), dtype=torch.float32, device="cuda")
+        d_hard = torch.empty((F, n), dtype=torch.uint8, device="cuda")
+        d_it = torch.empty(F, dtype=torch.int32, device="cuda")
+        d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
+        dec.gen_awgn_llr_dev(ebn0, seed, 0, F, d_llr.data_ptr(), stream)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dec.decode_batch_dev(d_llr.data_ptr(), F, iters, early, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr(), stream)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            _, ms, _ = dec.last_decode_timing()
+        mean_it = float(d_it.float().mean())
+        fer = float(d_hard.any(dim=1).float().mean())
+        del d_llr, d_hard, d_it, d_sw
+        return wall, ms / 1e3, mean_it, fer
+
+    def line(dec, F, iters, wall, launch_s, mean_it, fer, workload):
+        k = dec.n - dec.m
+        d = {"workload": workload, "value": F * k / wall / 1e9, "unit": "Gbit/s", "wall_ms": wall * 1e3, "launch_ms": launch_s * 1e3,
+             "kernel": dec.last_decode_kernel(), "mean_iterations": mean_it, "frame_error_rate": fer}
+        return d
+
+    # C1
+    m, n, rows, cols = L.codes.gallager(1024, 8, 2, seed=1)
+    dec = L.Decoder(m, n, rows, cols)
+    F, iters = 1 << 20, 50
+    wall, launch_s, mean_it, fer = run(dec, 3.0, F, iters, False, 11)
+    d = line(dec, F, iters, wall, launch_s, mean_it, fer,
+             "Gallager (8,2) n=1024 (the reference's default code), %d frames, %d fixed iterations, AWGN 3.0 dB" % (F, iters))
+    d["roofline"] = resident_roofline(F * dec.E * iters / launch_s)
+    out["c1"] = d
+    dec.close()
+    # C4
+    _, (m, n, rows, cols) = L.codes.nr_bg1_shaped(z=384, seed=1)
+    dec = L.Decoder(m, n, rows, cols)
+    F, iters = 1 << 16, 50
+    wall, launch_s, mean_it, fer = run(dec, 2.0, F, iters, False, 12)
+    d = line(dec, F, iters, wall, launch_s, mean_it, fer,
+             "NR-BG1-sized Z=384 (n=26112, E=%d), %d frames, %d fixed iterations, AWGN 2.0 dB" % (dec.E, F, iters))
+    b = F * algorithmic_bytes_per_frame(n, dec.E, iters)
+    d["roofline"] = {"bound": "hbm", "achieved": b / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": b / launch_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_decode": b,
+                     "note": "all sweep launches of the decode between two HIP events"}
+    out["c4"] = d
+    wall, launch_s, mean_it, fer = run(dec, 2.0, F, iters, True, 12)
+    out["c4_early_exit"] = line(dec, F, iters, wall, launch_s, mean_it, fer, "the same, early termination")
+    dec.close()
+    # C5
+    m, n, rows, cols = L.codes.regular_ldpc(64800, 3, 6, seed=1)
+    dec = L.Decoder(m, n, rows, cols)
+    for F in (1, 64):
+        wall, launch_s, mean_it, fer = run(dec, 1.6, F, 50, True, 13)
+        d = line(dec, F, 50, wall, launch_s, mean_it, fer,
+                 "regular (3,6) n=64800, %d frame(s), early termination (<= 50 iterations), AWGN 1.6 dB" % F)
+        d["latency_ms"] = wall * 1e3
+        b = F * algorithmic_bytes_per_frame(n, dec.E, 1) * mean_it
+        d["roofline"] = {"bound": "hbm", "achieved": b / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": b / launch_s / 1e9 / HBM_PEAK_GBS,
+                         "note": "latency-bound: the batch's whole state (%.1f MB) fits in the caches" % (F * dec.E * 4 / 1e6)}
+        out["c5_%d_frame%s" % (F, "" if F == 1 else "s")] = d
+    dec.close()
+    return out
+
+
 def algorithmic_bytes_per_frame(n, edges, iters, msg_bytes=4):
     """4*E*s + n*s per iteration: the CN sweep reads and writes E messages, the VN sweep reads
     and writes E messages and reads n channel LLRs."""
@@ -207,6 +311,8 @@ def main(argv=None):
                     help="auto: frame-resident kernel when the code fits in LDS; stream: force the frame-major HBM kernel")
     ap.add_argument("--no-stream-leg", action="store_true",
                     help="skip the extra single-step measurement of the streaming engine (N=1 only)")
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the short measurements of the other configurations (C1, C4, C5; N=1 only)")
     ap.add_argument("--plumbing-test", action="store_true",
                     help="no GPU: gloo backend, CPU tensors and a stand-in decoder; rehearses the stepping, the "
                          "all-reduce, the timing over ranks and the JSON line (tests/test_abi_and_host.py)")
@@ -334,27 +440,17 @@ def main(argv=None):
         # The messages of a frame stay in the LDS of one CU for all iterations: the algorithmic message bytes
         # never travel, so the HBM figure is an equivalent, not a fraction of a ceiling.  What bounds this
         # kernel is vector instruction issue; the LDS data path is the next ceiling.
-        valu_peak, lds_peak = resident_ceilings()
         edge_iters = frames_per_launch * dec.E * iters / launch_s if launch_s > 0 else 0.0
         hbm_equivalent["note"] = ("algorithmic message bytes / time; they stay in LDS, so this exceeds the HBM peak "
                                   "and `traffic` (measured HBM bytes per launch) is far below it")
-        roofline = {
-            "bound": "valu_issue", "achieved": edge_iters / 1e12, "peak": valu_peak / 1e12, "unit": "Tedge-iterations/s",
-            "frac": edge_iters / valu_peak,
-            "peak_definition": "1024 SIMDs x 2.4 GHz x 64 lanes / %.1f issue cycles per 64 edge-iterations "
-                               "(4 transcendentals x %.1f cycles + 12 fp32 operations x %.3f cycles, the issue rates "
-                               "measured by tools/valu_rates.hip)"
-                               % (VALU_FLOOR_CYCLES_PER_64_EDGE_ITERS, TRANS_CYCLES, FP32_ELEMENT_CYCLES),
-            "lds_ceiling": {"peak": lds_peak / 1e12, "unit": "Tedge-iterations/s", "frac": edge_iters / lds_peak,
-                            "peak_definition": "256 CUs x 2.4 GHz / %.3f LDS cycles per edge-iteration (b128 read and "
-                                               "write on the check side, b32 read and write on the variable side)"
-                                               % LDS_FLOOR_CYCLES_PER_EDGE_ITER},
+        roofline = resident_roofline(edge_iters)
+        roofline.update({
             "traffic": measured_traffic(kernel, F, iters, n),
             "kernel": kernel, "launch_ms": launch_s * 1e3,
             "edge_iterations_per_launch": frames_per_launch * dec.E * iters,
             "hbm_equivalent": hbm_equivalent,
             "issue_from_committed_profile": measured_issue_rates(kernel),
-        }
+        })
     else:
         roofline = dict(hbm_equivalent, traffic=measured_traffic(kernel, F, iters, n), kernel=kernel,
                         launch_ms=launch_s * 1e3, note="frame-major streaming kernel: HBM-bound")
@@ -420,6 +516,12 @@ def main(argv=None):
                          "traffic": measured_traffic(dec.last_decode_kernel(), F, iters, n),
                          "kernel": dec.last_decode_kernel(), "launch_ms": ms / max(nl, 1)},
         }
+    if world == 1 and not plumbing and not args.no_config_legs and args.n == 4096:
+        # free the headline batch first: the C4 leg needs 47 GB of its own
+        del d_llr, d_hard, d_it, d_sw
+        dec.close()
+        torch.cuda.empty_cache()
+        out["configs"] = other_configs(L, torch, stream)
     if rank == 0:
         if world == 1 and args.cpu_seconds > 0 and not plumbing:
             out["cpu_baseline"] = cpu_baseline(code, args.ebn0, iters, args.cpu_seconds)

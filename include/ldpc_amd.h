@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LDPC_AMD_VERSION 110 /* 0.1.10 */
+#define LDPC_AMD_VERSION 120 /* 0.1.20 */
 
 /* error codes */
 #define LDPC_AMD_OK 0
@@ -150,11 +150,17 @@ int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
                                                 degree 1 alone (same results, less traffic); 0 = every sweep touches them */
 #define LDPC_AMD_OPT_TUNE_SIM_CHUNK_MB 113   /* ldpc_amd_simulate: MiB of received and decoded words per chunk of a leg (default 2048;
                                                 a leg holds two such sets when its chunks overlap) */
+#define LDPC_AMD_OPT_TUNE_NODES_FLAT_BARRIER 114 /* node-parallel kernel: 1 = every grid barrier is the one-level one (each workgroup
+                                                releases and arrives at one counter); 0 (default) = workgroups meet per XCD first.
+                                                Same results; the A/B also checks the two-level barrier's visibility assumptions */
 #define LDPC_AMD_OPT_TEST_NODES_OVERSIZE 190 /* tests: ask for a cooperative grid the runtime must refuse */
+#define LDPC_AMD_OPT_TEST_NODES_TIMEOUT 191  /* tests: start the node-parallel kernel with its barrier time-out flag raised */
 /* read-only */
 #define LDPC_AMD_OPT_NODES_REFUSALS 200      /* cooperative launches the runtime refused on this context */
 #define LDPC_AMD_OPT_NODES_LAST_HIP_ERROR 201 /* hipError_t of the last refusal (0 = none) */
 #define LDPC_AMD_OPT_NOALLOC_MAX_FRAMES 202  /* largest batch ldpc_amd_decode_batch_dev_noalloc takes for this code */
+#define LDPC_AMD_OPT_NODES_BARRIER_TIMED_OUT 203 /* 1 if a grid barrier of the most recent node-parallel launch ("bp_nodes_kernel")
+                                                gave up waiting; read it after synchronising the stream of a "_dev" decode (see below) */
 
 #define LDPC_AMD_ENGINE_AUTO 0    /* frame-resident kernels where the code fits in LDS, else streaming */
 #define LDPC_AMD_ENGINE_GENERIC 1 /* as AUTO, but never the kernels specialised for (6,3) / (8,2) codes */
@@ -184,20 +190,32 @@ int ldpc_amd_decode_batch(ldpc_amd_ctx* ctx, const float* llr, int64_t frames, i
 int ldpc_amd_decode_batch_dev(ldpc_amd_ctx* ctx, const float* d_llr, int64_t frames, int32_t max_iters,
                               int32_t early_term, uint8_t* d_hard, int32_t* d_iters,
                               int32_t* d_syndrome_weight, void* stream);
+/*
+ * A "_dev" decode only enqueues work, so it cannot report what happens while that work runs.  One such event
+ * exists: a batch of at most 32 frames of a code that does not fit in LDS runs in one cooperative launch whose
+ * grid-wide barriers are bounded waits (about 0.2 s); if one gives up (it never has on a healthy device), the
+ * launch finishes with invalid results and marks them: iters[f] = syndrome_weight[f] = -1 for every frame of
+ * the batch, and ldpc_amd_get_option(LDPC_AMD_OPT_NODES_BARRIER_TIMED_OUT) returns 1.  After synchronising the
+ * stream, a "_dev" caller checks either.  The host-pointer entry points, ldpc_amd_simulate and
+ * ldpc_amd_last_decode_timing check for it themselves and fail with LDPC_AMD_EHIP.
+ */
 
 /*
- * ldpc_amd_decode_batch_dev for callers that cannot allocate device memory while they decode: code under
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
+ * ldpc_amd_decode_batch_dev for callers that cannot allocate device memory while they decode: tight
+ * serving loops, harnesses that forbid hipMalloc, code that must not wait for the allocator (it has not been run
+ * under HIP graph capture).  It has no counterpart in the
  * reference (whose decode() allocates all of its state per call, LogDecoder.java:57-58).  Same arguments,
  * same outputs bit for bit; it calls no hipMalloc / hipFree or other allocating routine.  The frame-major
  * message, LLR, decision and per-frame state arrays of the sweep kernels ("rows_cn_kernel"), which the
  * other entry points keep in a workspace they allocate, live in a static device array of
  * LDPC_AMD_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
- * Limits: the batch must fit into that array in one piece, (E + n + ceil(n/32) + 4) * 256 bytes per 64
+ * Limits: the batch must fit into that array in one piece, (E + n + ceil(n/32) + 5) * 256 bytes per 64
  * frames -- 1,984 frames of a (3,6) n = 4096 code, 192 of an NR-BG1-sized Z = 384 code, 128 of an
  * n = 64800 (3,6) code (ldpc_amd_get_option(LDPC_AMD_OPT_NOALLOC_MAX_FRAMES) gives the number for the
  * context's code); a larger batch fails with LDPC_AMD_ELIMIT and nothing is launched.  The engine options
- * are not consulted (always the sweep launches, one frame per lane).  All calls on one GPU, from any
+ * are not consulted (always the sweep launches, one frame per lane); of the tuning options the sweeps' own still
+ * apply (LDPC_AMD_OPT_TUNE_ROWS_WAVES, _ROWS_FUSED, _ROWS_LEAVES), with identical results for every setting.  It
+ * records no timing events: ldpc_amd_last_decode_timing reports 0 launches after it.  All calls on one GPU, from any
  * context, share that GPU's array: calls that overlap in time on one GPU race, so the caller serialises
  * them (one stream, or events between streams).  The array keeps the last call's contents; what must
  * start at zero is cleared on the stream at the start of each call.
@@ -229,6 +247,8 @@ int ldpc_amd_decode_bsc_batch_dev(ldpc_amd_ctx* ctx, const uint8_t* d_r, int64_t
  * again the all-zero word.  Replaces the per-frame "c = GenerateC.geneC(encodedG)" of
  * LDPC_GallagerIntStreamSimu.java:115 together with ldpc_amd_gen_codewords_dev.
  */
+#define LDPC_AMD_MAX_GENERATOR_ROWS 10176 /* larger k fails with LDPC_AMD_ELIMIT: the codeword kernel keeps the message bits
+                                            of 64 frames in one workgroup's LDS */
 int ldpc_amd_set_generator(ldpc_amd_ctx* ctx, int32_t k, const uint8_t* G);
 
 /*
@@ -277,6 +297,18 @@ int ldpc_amd_count_errors_dev(ldpc_amd_ctx* ctx, int64_t frames, const uint8_t* 
  */
 int ldpc_amd_simulate(ldpc_amd_ctx* ctx, int32_t channel, double param, uint64_t seed, int64_t first_frame,
                       int64_t frames, int32_t max_iters, int32_t early_term, uint64_t* counters);
+
+/*
+ * The same leg with the counters kept on the device: the counts of frames first_frame .. first_frame+frames-1 are
+ * ADDED into d_counters (LDPC_AMD_CNT_FIXED + max_iters uint64 on the context's GPU) by the kernels, nothing is
+ * copied to the host and the call does not wait for the GPU (apart from buffer allocations on its first use at
+ * a given size).  The leg is ordered after the work already enqueued on `stream` (NULL = default stream), and
+ * work enqueued on `stream` after the call is ordered after the leg, so a multi-GPU caller all-reduces
+ * d_counters in place (one collective per batch instead of the reference's synchronized(lock),
+ * LDPC_GallagerIntStreamSimu.java:139-183) and reads back the one word its stop rule needs.
+ */
+int ldpc_amd_simulate_dev(ldpc_amd_ctx* ctx, int32_t channel, double param, uint64_t seed, int64_t first_frame,
+                          int64_t frames, int32_t max_iters, int32_t early_term, uint64_t* d_counters, void* stream);
 
 /*
  * Page-locked host memory for the host-pointer entry points above.  They accept any host memory; from

@@ -26,10 +26,11 @@ CNT_FIXED = 16
 OPT = {
     "engine": 1, "stream_kernel": 2, "nodes": 3, "sim_overlap": 4, "verbose": 5, "sim_fused": 6,
     "lds_wpe": 100, "lds_fpw": 101, "generic_lds_kb": 102, "nodes_blocks": 103, "fpl": 104, "layout": 105,
-    "rows_waves": 106, "wps": 107, "nopipe": 108, "rows_fused": 109, "generic_threads": 110, "lds_vpt": 111, "rows_leaves": 112, "sim_chunk_mb": 113, "test_nodes_oversize": 190,
-    "nodes_refusals": 200, "nodes_last_hip_error": 201, "noalloc_max_frames": 202,
+    "rows_waves": 106, "wps": 107, "nopipe": 108, "rows_fused": 109, "generic_threads": 110, "lds_vpt": 111, "rows_leaves": 112, "sim_chunk_mb": 113, "nodes_flat_barrier": 114,
+    "test_nodes_oversize": 190, "test_nodes_timeout": 191,
+    "nodes_refusals": 200, "nodes_last_hip_error": 201, "noalloc_max_frames": 202, "nodes_barrier_timed_out": 203,
 }
-OPT_READ_ONLY = ("nodes_refusals", "nodes_last_hip_error", "noalloc_max_frames")
+OPT_READ_ONLY = ("nodes_refusals", "nodes_last_hip_error", "noalloc_max_frames", "nodes_barrier_timed_out")
 OPT_LIBRARY_DEFAULT = {"nodes": -1, "sim_overlap": 1, "sim_fused": 1, "rows_leaves": 1, "sim_chunk_mb": 2048}   # every other option defaults to 0
 ENGINE_AUTO, ENGINE_GENERIC, ENGINE_STREAM = 0, 1, 2
 ENGINES = {"auto": ENGINE_AUTO, "generic": ENGINE_GENERIC, "stream": ENGINE_STREAM}
@@ -78,6 +79,7 @@ SIGNATURES = {
     "ldpc_amd_gen_awgn_llr_dev": (C.c_int, [_vp, _f64, _u64, _i64, _i64, _vp, _vp, _vp]),
     "ldpc_amd_count_errors_dev": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "ldpc_amd_simulate": (C.c_int, [_vp, _i32, _f64, _u64, _i64, _i64, _i32, _i32, _vp]),
+    "ldpc_amd_simulate_dev": (C.c_int, [_vp, _i32, _f64, _u64, _i64, _i64, _i32, _i32, _vp, _vp]),
     "ldpc_amd_last_decode_timing": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ldpc_amd_last_decode_kernel": (C.c_char_p, [_vp]),
 }
@@ -305,6 +307,14 @@ class Decoder:
                                                 int(frames), int(max_iters), int(bool(early_term)), _np_ptr(counters)))
         return counters
 
+    def simulate_dev(self, channel, param, seed, first_frame, frames, max_iters, early_term, d_counters, stream=0):
+        """simulate() with the counters added into a device vector (address of 16 + max_iters 64-bit words);
+        nothing is copied to the host and the call does not wait for the GPU."""
+        self._sync_options()
+        self._check(self._lib.ldpc_amd_simulate_dev(self._h, int(channel), float(param), int(seed), int(first_frame),
+                                                    int(frames), int(max_iters), int(bool(early_term)), d_counters,
+                                                    stream or None))
+
     # ---- device-pointer entry points (addresses as ints, e.g. torch.Tensor.data_ptr()) ---
     def decode_batch_dev(self, d_llr, frames, max_iters, early_term, d_hard, d_iters=0, d_synd=0, stream=0):
         self._sync_options()
@@ -315,6 +325,7 @@ class Decoder:
     def decode_batch_dev_noalloc(self, d_llr, frames, max_iters, early_term, d_hard, d_iters=0, d_synd=0, stream=0):
         """decode_batch_dev on the library's static device scratch array: allocates nothing, takes at most
         get_option("noalloc_max_frames") frames."""
+        self._sync_options()
         self._check(self._lib.ldpc_amd_decode_batch_dev_noalloc(self._h, d_llr, int(frames), int(max_iters),
                                                                 int(bool(early_term)), d_hard, d_iters or None,
                                                                 d_synd or None, stream or None))

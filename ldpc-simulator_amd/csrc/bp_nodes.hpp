@@ -39,6 +39,7 @@ struct NodesParams {
     float l0, l1, scale;
     int g_length;
     int frames, max_iters, early;
+    int flat_barrier;    // 1: every grid barrier is the one-level one (nodes_grid_barrier_flat); results identical
     float* msg;          // [frames][E]
     float* lam;          // [frames][n]
     int32_t* synd_acc;   // [frames][max_iters], zero on entry
@@ -75,7 +76,8 @@ __device__ __forceinline__ void nodes_syndrome(const NodesParams& p, int f, int 
 // bar[0] grid counter, bar[1] time-out flag, bar[2..9] arrivals per XCD, bar[10..17] workgroups per XCD; all
 // zero on entry, all monotonic.  The grid is launched cooperatively, so all workgroups are resident and the
 // waits end; they are bounded all the same (about 0.2 s): a time-out raises bar[1], every later barrier falls
-// through at once, the kernel finishes with meaningless results and the host reports the flag as an error.
+// through at once, the kernel finishes with meaningless results, writes -1 into every frame's iteration count and
+// syndrome weight, and the host reports the flag as an error.
 __device__ __forceinline__ void nodes_poll(unsigned* bar, unsigned target) {
     unsigned spins = 0;
     while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -107,9 +109,14 @@ struct NodesBarrier {
     unsigned grid_target;   // value of bar[0] once everyone has passed the next barrier
     unsigned xcd_target;    // value of bar[2 + xcd] once every workgroup of this XCD has arrived
     unsigned xcd, xcd_blocks, xcds;
+    unsigned flat, blocks;  // flat: the one-level barrier over all `blocks` workgroups instead (A/B and tests)
 };
 
 __device__ __forceinline__ void nodes_grid_barrier(NodesBarrier& b) {
+    if (b.flat) {  // grid-uniform
+        nodes_grid_barrier_flat(b.bar, b.grid_target, b.blocks);
+        return;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -166,6 +173,8 @@ __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
     nodes_grid_barrier_flat(p.bar, nb.grid_target, gridDim.x);
     nb.xcd_target = 0u;
     nb.xcds = 0u;
+    nb.flat = p.flat_barrier ? 1u : 0u;
+    nb.blocks = gridDim.x;
     for (unsigned x = 0; x < 8u; ++x) {
         const unsigned cnt = __hip_atomic_load(&p.bar[10 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nb.xcds += cnt != 0u;
@@ -229,6 +238,14 @@ __global__ void __launch_bounds__(256) bp_nodes_kernel(NodesParams p) {
                 if (p.out_iters) p.out_iters[f] = L;
                 if (p.out_synd) p.out_synd[f] = p.synd_acc[(long long)f * L + (L - 1)];
             }
+        }
+    }
+    // a barrier timed out somewhere: nothing this launch wrote can be trusted, and a caller that only looks at its
+    // own buffers must see that too
+    if (gtid == 0 && __hip_atomic_load(&p.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        for (int f = 0; f < p.frames; ++f) {
+            if (p.out_iters) p.out_iters[f] = -1;
+            if (p.out_synd) p.out_synd[f] = -1;
         }
     }
 }

@@ -35,7 +35,7 @@ struct Options {
     int verbose = 0;
     int lds_wpe = 0, lds_fpw = 0, generic_lds_kb = 0, nodes_blocks = 0, fpl = 0, layout = 0, rows_waves = 0, wps = 0,
         nopipe = 0, rows_fused = -1, generic_threads = 0, lds_vpt = 0;
-    int test_nodes_oversize = 0;
+    int test_nodes_oversize = 0, test_nodes_timeout = 0, nodes_flat = 0;
 };
 
 struct ldpc_amd_ctx {
@@ -63,6 +63,7 @@ struct ldpc_amd_ctx {
     size_t stage_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipStream_t io_stream[2] = {nullptr, nullptr};
     hipEvent_t io_decoded[2] = {nullptr, nullptr};
+    hipEvent_t sim_enter = nullptr;  // ldpc_amd_simulate_dev: the caller's stream at the time of the call
     unsigned long long* d_counters = nullptr;
     size_t counters_len = 0;
     // generator matrix for random codewords, by columns: n columns of ceil(k / 64) words, row i at bit i & 63
@@ -779,6 +780,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
             q.scale = (float)llr_scale(c);
             q.frames = (int)frames; q.max_iters = max_iters; q.early = early ? 1 : 0;
+            q.flat_barrier = c->opt.nodes_flat ? 1 : 0;
             q.msg = (float*)c->ws;
             q.lam = q.msg + F * (size_t)c->E;
             q.synd_acc = (int32_t*)(q.lam + F * (size_t)n);
@@ -786,6 +788,8 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             c->nodes_bar = q.bar;
             q.hard = d_hard; q.out_iters = d_iters; q.out_synd = d_synd;
             LDPC_HIP(c, hipMemsetAsync(q.synd_acc, 0, (F * (size_t)max_iters + kNodesBarWords) * sizeof(int32_t), s));
+            // tests: the time-out flag already raised, as if a barrier of this launch had given up
+            if (c->opt.test_nodes_timeout) LDPC_HIP(c, hipMemsetAsync(q.bar + 1, 1, 1, s));
             NodesLaunch l;
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
                      : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
@@ -874,7 +878,6 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
                             std::to_string((size_t)LDPC_AMD_NOALLOC_SCRATCH_BYTES) + " (at most " +
                             std::to_string((long long)(LDPC_AMD_NOALLOC_SCRATCH_BYTES / per_tile) * T) + " frames per call)");
         if (!c->scratch_ptr) return fail(c, LDPC_AMD_EHIP, "decode_batch_dev_noalloc: no scratch address for this device");
-        if (c->ev.size() < 2) return fail(c, LDPC_AMD_EHIP, "decode_batch_dev_noalloc: timing events missing");
         ws = c->scratch_ptr;
     } else {
         if (c->ws_bytes < need) {
@@ -889,7 +892,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         ws = c->ws;
     }
     c->last_kernel = "bp_decode_kernel";
-    while ((long long)c->ev.size() < 2 * std::min<long long>(rounds, 256)) {
+    while (!noalloc && (long long)c->ev.size() < 2 * std::min<long long>(rounds, 256)) {
         hipEvent_t e;
         LDPC_HIP(c, hipEventCreate(&e));
         c->ev.push_back(e);
@@ -974,7 +977,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             }
             LDPC_HIP(c, hipGetLastError());
         }
-        const bool timed = r < 256;
+        const bool timed = r < 256 && !noalloc;  // the no-allocation path records nothing on the caller's stream but its work
         if (timed) LDPC_HIP(c, hipEventRecord(c->ev[(size_t)(2 * r)], s));
         if (by_rows) {
             RowsParams q{};
@@ -1224,6 +1227,7 @@ int ldpc_amd_destroy(ldpc_amd_ctx* c) {
             if (c->io_stream[i]) (void)hipStreamDestroy(c->io_stream[i]);
             if (c->io_decoded[i]) (void)hipEventDestroy(c->io_decoded[i]);
         }
+        if (c->sim_enter) (void)hipEventDestroy(c->sim_enter);
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -1296,9 +1300,12 @@ int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
         case LDPC_AMD_OPT_TUNE_LDS_VPT: if (!(value == 0 || value == 8 || value == 12 || value == 16)) break; o.lds_vpt = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: if (!(value == 0 || (value >= 64 && value <= 512 && value % 64 == 0))) break; o.generic_threads = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: if (!range(0, 1)) break; o.test_nodes_oversize = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TEST_NODES_TIMEOUT: if (!range(0, 1)) break; o.test_nodes_timeout = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_NODES_FLAT_BARRIER: if (!range(0, 1)) break; o.nodes_flat = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_NODES_REFUSALS:
         case LDPC_AMD_OPT_NODES_LAST_HIP_ERROR:
         case LDPC_AMD_OPT_NOALLOC_MAX_FRAMES:
+        case LDPC_AMD_OPT_NODES_BARRIER_TIMED_OUT:
             return fail(c, LDPC_AMD_EINVAL, "set_option: key " + std::to_string(key) + " is read-only");
         default: return fail(c, LDPC_AMD_EINVAL, "set_option: unknown key " + std::to_string(key));
     }
@@ -1330,6 +1337,20 @@ int ldpc_amd_get_option(const ldpc_amd_ctx* c, int32_t key, int64_t* value) {
         case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: *value = o.generic_threads; break;
         case LDPC_AMD_OPT_TUNE_LDS_VPT: *value = o.lds_vpt; break;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: *value = o.test_nodes_oversize; break;
+        case LDPC_AMD_OPT_TEST_NODES_TIMEOUT: *value = o.test_nodes_timeout; break;
+        case LDPC_AMD_OPT_TUNE_NODES_FLAT_BARRIER: *value = o.nodes_flat; break;
+        case LDPC_AMD_OPT_NODES_BARRIER_TIMED_OUT: {
+            // the flag of the most recent node-parallel launch; the caller has synchronised the stream it ran on
+            *value = 0;
+            if (c->nodes_bar && c->timed_launches && !strcmp(c->last_kernel, "bp_nodes_kernel")) {
+                DeviceGuard guard(c->device);
+                unsigned flag = 0;
+                if (!guard.ok || hipMemcpy(&flag, c->nodes_bar + 1, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess)
+                    return LDPC_AMD_EHIP;
+                *value = flag ? 1 : 0;
+            }
+            break;
+        }
         case LDPC_AMD_OPT_NODES_REFUSALS: *value = c->nodes_refusals; break;
         case LDPC_AMD_OPT_NODES_LAST_HIP_ERROR: *value = c->nodes_last_error; break;
         case LDPC_AMD_OPT_NOALLOC_MAX_FRAMES:
@@ -1456,6 +1477,9 @@ int ldpc_amd_set_generator(ldpc_amd_ctx* c, int32_t k, const uint8_t* G) {
     }
     if (k == 0 || !G) return LDPC_AMD_OK;
     if (k < 0) return fail(c, LDPC_AMD_EINVAL, "set_generator: k must be >= 0");
+    if (gen_codewords_lds_bytes(k) > 160 * 1024)
+        return fail(c, LDPC_AMD_ELIMIT, "set_generator: generator matrices of more than " + std::to_string(LDPC_AMD_MAX_GENERATOR_ROWS) +
+                                            " rows are not supported (the codeword kernel keeps the message bits of 64 frames in LDS)");
     const size_t kw64 = ((size_t)k + 63) / 64;
     std::vector<unsigned long long> packed((size_t)c->n * kw64, 0ull);
     for (int i = 0; i < k; ++i)
@@ -1506,23 +1530,12 @@ int ldpc_amd_count_errors_dev(ldpc_amd_ctx* c, int64_t frames, const uint8_t* d_
                         (unsigned long long*)d_counters, (hipStream_t)stream);
 }
 
-int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t seed, int64_t first_frame,
-                      int64_t frames, int32_t max_iters, int32_t early_term, uint64_t* counters) {
-    if (!c) return LDPC_AMD_EINVAL;
-    if (frames < 0 || max_iters < 0 || !counters) return fail(c, LDPC_AMD_EINVAL, "simulate: bad argument");
-    if (channel != LDPC_AMD_CH_BSC_INFO && channel != LDPC_AMD_CH_BSC_ALL && channel != LDPC_AMD_CH_AWGN)
-        return fail(c, LDPC_AMD_EINVAL, "simulate: unknown channel");
-    DeviceGuard guard(c->device);
-    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+// One leg: generate, decode, count, in chunks.  The counters of the chunks are added into `d_cnt` (device) by the
+// kernels themselves.  With `user` set (ldpc_amd_simulate_dev) the leg is ordered after the work already on
+// that stream and the stream waits for the leg; otherwise the caller synchronises.
+static int simulate_leg(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t seed, int64_t first_frame, int64_t frames,
+                        int32_t max_iters, int32_t early_term, unsigned long long* d_cnt, bool ordered, hipStream_t user) {
     const size_t n = (size_t)c->n;
-    const size_t nc = (size_t)LDPC_AMD_CNT_FIXED + (size_t)max_iters;
-    if (c->counters_len < nc) {
-        if (c->d_counters) LDPC_HIP(c, hipFree(c->d_counters));
-        c->d_counters = nullptr;
-        LDPC_HIP(c, hipMalloc((void**)&c->d_counters, nc * sizeof(unsigned long long)));
-        c->counters_len = nc;
-    }
-    LDPC_HIP(c, hipMemset(c->d_counters, 0, nc * sizeof(unsigned long long)));
     double l0 = 0.0, l1 = 0.0;
     const bool awgn = channel == LDPC_AMD_CH_AWGN;
     if (!awgn) {
@@ -1539,9 +1552,15 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
     // and the error accounting of chunk i - 1 (HBM-bound, no LDS) run in the wave slots the resident
     // decode kernel of chunk i (VALU-bound, all of the LDS) leaves free.  Engines that keep their
     // messages in the context's one workspace must not overlap: they stay on one stream and one set.
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (!c->io_stream[i]) LDPC_HIP(c, hipStreamCreateWithFlags(&c->io_stream[i], hipStreamNonBlocking));
-    LDPC_HIP(c, hipStreamSynchronize(nullptr));  // the counters are zero before the other streams add to them
+        if (!c->io_decoded[i]) LDPC_HIP(c, hipEventCreateWithFlags(&c->io_decoded[i], hipEventDisableTiming));
+    }
+    if (ordered) {
+        if (!c->sim_enter) LDPC_HIP(c, hipEventCreateWithFlags(&c->sim_enter, hipEventDisableTiming));
+        LDPC_HIP(c, hipEventRecord(c->sim_enter, user));
+        for (int i = 0; i < 2; ++i) LDPC_HIP(c, hipStreamWaitEvent(c->io_stream[i], c->sim_enter, 0));
+    }
     bool overlap = false;
     long long index = 0;
     for (long long f0 = 0; f0 < frames; f0 += chunk, ++index) {
@@ -1581,25 +1600,70 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
         if (rc) return rc;
         // the frame-resident kernels of the (6,3) and (8,2) codes count the errors themselves; for every other
         // engine the accounting is a pass of its own over the decoder's outputs
-        CountArgs count{cw, c->d_counters, true, false};
+        CountArgs count{cw, d_cnt, true, false};
         rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)st[1], (int32_t*)st[2], (int32_t*)st[3], s, false, &count);
         if (rc) return rc;
+        if (!strcmp(c->last_kernel, "bp_nodes_kernel")) {
+            // a chunk of a few frames went through the cooperative kernel: its barriers are bounded waits, and a
+            // wait that gave up must not be counted as a decode
+            LDPC_HIP(c, hipStreamSynchronize(s));
+            if (int brc = check_nodes_barrier(c)) return brc;
+        }
         if (!count.done)
             rc = count_launch(c, nf, (const uint8_t*)st[1], cw, awgn ? nullptr : (const uint8_t*)st[0],
                               awgn ? (const float*)st[0] : nullptr, (const int32_t*)st[2], (const int32_t*)st[3], max_iters,
-                              c->d_counters, s);
+                              d_cnt, s);
         if (rc) return rc;
         if (index == 0) {
             const char* k = c->last_kernel;
             overlap = k && (!strcmp(k, "bp_lds_kernel") || !strcmp(k, "bp_lds_gen_kernel")) && c->opt.sim_overlap != 0;
         }
     }
+    if (ordered)
+        for (int i = 0; i < 2; ++i) {
+            LDPC_HIP(c, hipEventRecord(c->io_decoded[i], c->io_stream[i]));
+            LDPC_HIP(c, hipStreamWaitEvent(user, c->io_decoded[i], 0));
+        }
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t seed, int64_t first_frame,
+                      int64_t frames, int32_t max_iters, int32_t early_term, uint64_t* counters) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (frames < 0 || max_iters < 0 || !counters) return fail(c, LDPC_AMD_EINVAL, "simulate: bad argument");
+    if (channel != LDPC_AMD_CH_BSC_INFO && channel != LDPC_AMD_CH_BSC_ALL && channel != LDPC_AMD_CH_AWGN)
+        return fail(c, LDPC_AMD_EINVAL, "simulate: unknown channel");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    const size_t nc = (size_t)LDPC_AMD_CNT_FIXED + (size_t)max_iters;
+    if (c->counters_len < nc) {
+        if (c->d_counters) LDPC_HIP(c, hipFree(c->d_counters));
+        c->d_counters = nullptr;
+        LDPC_HIP(c, hipMalloc((void**)&c->d_counters, nc * sizeof(unsigned long long)));
+        c->counters_len = nc;
+    }
+    LDPC_HIP(c, hipMemset(c->d_counters, 0, nc * sizeof(unsigned long long)));
+    LDPC_HIP(c, hipStreamSynchronize(nullptr));  // the counters are zero before the other streams add to them
+    if (int rc = simulate_leg(c, channel, param, seed, first_frame, frames, max_iters, early_term, c->d_counters, false, nullptr))
+        return rc;
     LDPC_HIP(c, hipStreamSynchronize(c->io_stream[0]));
     LDPC_HIP(c, hipStreamSynchronize(c->io_stream[1]));
     std::vector<unsigned long long> h(nc);
     LDPC_HIP(c, hipMemcpy(h.data(), c->d_counters, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < nc; ++i) counters[i] += h[i];
     return LDPC_AMD_OK;
+}
+
+int ldpc_amd_simulate_dev(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t seed, int64_t first_frame,
+                          int64_t frames, int32_t max_iters, int32_t early_term, uint64_t* d_counters, void* stream) {
+    if (!c) return LDPC_AMD_EINVAL;
+    if (frames < 0 || max_iters < 0 || !d_counters) return fail(c, LDPC_AMD_EINVAL, "simulate_dev: bad argument");
+    if (channel != LDPC_AMD_CH_BSC_INFO && channel != LDPC_AMD_CH_BSC_ALL && channel != LDPC_AMD_CH_AWGN)
+        return fail(c, LDPC_AMD_EINVAL, "simulate_dev: unknown channel");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, LDPC_AMD_EHIP, "hipSetDevice failed");
+    return simulate_leg(c, channel, param, seed, first_frame, frames, max_iters, early_term,
+                        (unsigned long long*)d_counters, true, (hipStream_t)stream);
 }
 
 int ldpc_amd_host_alloc(uint64_t bytes, void** out) {

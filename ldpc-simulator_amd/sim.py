@@ -47,21 +47,64 @@ def simulate_sharded(simulate_fn, first_frame, frames, max_iters, rank=0, world=
 
 
 def simulate_until(simulate_fn, max_iters, min_frame_errors=100, max_frames=10 ** 8, batch=1 << 20, first_frame=0,
-                   rank=0, world=1, device=None):
+                   rank=0, world=1, device=None, accumulate_fn=None, always_reduce=False):
     """One point of an error-rate curve: decode batches of `batch` frames (sharded over the ranks, global
     frame indices first_frame, first_frame + 1, ...) until at least `min_frame_errors` frames have failed or
     `max_frames` have been decoded, whichever comes first.  The counters are all-reduced after every batch,
-    so every rank takes the same decision to stop; the frames decoded, and so the result, do not depend on
-    the number of ranks.  Returns the summed counter vector."""
-    total = np.zeros(capi.CNT_FIXED + int(max_iters), np.uint64)
+    so every rank takes the same decision to stop; the frames decoded, and so the result, depend on `batch`
+    (the stop rule is looked at once per batch) but not on the number of ranks.  Returns the summed counter
+    vector (numpy uint64).
+
+    Two ways to run a rank's share of a batch:
+      * simulate_fn(first, count) -> uint64[16 + max_iters] on the host (Decoder.simulate; CPU stand-ins in tests);
+      * accumulate_fn(first, count, tensor): ADD the share's counters into `tensor` (int64[16 + max_iters] on
+        `device`) without waiting for them (Decoder.simulate_dev, see device_accumulator).  Then the counters
+        never leave the device: the batch's vector is all-reduced in place, added to the running total there,
+        and one word (the frame errors so far) is read back per batch for the stop rule.
+    A caller that wants a rank's share to stay large as ranks are added scales `batch` itself (tools/run_c3_sweep.py
+    uses world x 2^20)."""
+    if accumulate_fn is None:
+        total = np.zeros(capi.CNT_FIXED + int(max_iters), np.uint64)
+        done = 0
+        while done < max_frames:
+            count = int(min(batch, max_frames - done))
+            total += simulate_sharded(simulate_fn, first_frame + done, count, max_iters, rank, world, device)
+            done += count
+            if int(total[capi.CNT_FRAME_ERRORS]) >= min_frame_errors:
+                break
+        return total
+    import torch
+    import torch.distributed as dist
+
+    reduce = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or always_reduce)
+    total = torch.zeros(capi.CNT_FIXED + int(max_iters), dtype=torch.int64, device=device)
+    local = torch.zeros_like(total)
     done = 0
     while done < max_frames:
         count = int(min(batch, max_frames - done))
-        total += simulate_sharded(simulate_fn, first_frame + done, count, max_iters, rank, world, device)
+        start, share = shard_range(first_frame + done, count, rank, world)
+        local.zero_()
+        if share > 0:
+            accumulate_fn(start, share, local)
+        if reduce:
+            dist.all_reduce(local, op=dist.ReduceOp.SUM)
+        total += local
         done += count
-        if int(total[capi.CNT_FRAME_ERRORS]) >= min_frame_errors:
+        if int(total[capi.CNT_FRAME_ERRORS].item()) >= min_frame_errors:     # the one word that crosses to the host
             break
-    return total
+    return total.cpu().numpy().astype(np.uint64)
+
+
+def device_accumulator(dec, channel, param, seed, max_iters, early_term=True):
+    """accumulate_fn for simulate_until on a GPU: a rank's share of a batch through ldpc_amd_simulate_dev on the
+    current torch stream, counters added into the given device tensor."""
+    import torch
+
+    def accumulate(first, count, tensor):
+        assert tensor.dtype == torch.int64 and tensor.is_cuda and tensor.numel() >= capi.CNT_FIXED + int(max_iters)
+        dec.simulate_dev(channel, param, seed, first, count, max_iters, early_term, tensor.data_ptr(),
+                         torch.cuda.current_stream().cuda_stream)
+    return accumulate
 
 
 def rates(counters, m, n):

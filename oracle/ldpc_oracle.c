@@ -161,9 +161,28 @@ static inline double ref_signum(double x) { return (x > 0.0) ? 1.0 : (x < 0.0) ?
  * alpha/beta are indexed by CSR edge id instead of [m][n]/[n][m]; every sum and
  * product visits the same neighbours in the same ascending order and skips the
  * target edge instead of subtracting/dividing it out (LogDecoder.java:67-95). */
-static int decode_sparse(const oracle_graph* g, const double* lambda, int max_iters, int early_term,
-                         int cn_rule, uint8_t* hard, int32_t* iters_out, int32_t* synd_out,
-                         double* alpha, double* beta, double* th, ulp_noise* nz) {
+/* What a message array of 4-byte floats keeps of a double: `storage` 0 = the double itself (the
+ * reference, LogDecoder.java:57-58), 1 = rounded to float, 2 = rounded to float after scaling to bits
+ * (x / ln 2), the unit an implementation built on exp2/log2 stores.  All arithmetic stays double, so a
+ * run with storage 1 or 2 shows what float STORAGE alone does to a decode.  Two more bits switch single
+ * parts of the arithmetic to float, in the association a prefix / suffix implementation uses (they need
+ * storage 2): +4 = the variable-node sums (prefix from lambda upwards, suffix from the last neighbour
+ * downwards, beta = prefix + suffix), +8 = the check-node rule on complements, q = 1 - tanh(|beta|/2) =
+ * 1 / (0.5 * 2^|beta| + 0.5), Q <- Q + q (1 - Q) for prefix and suffix, |alpha| = log2(2/Q - 1), with
+ * correctly rounded float exp2 / log2 / division.  A model of a float implementation, not the reference. */
+#define MODEL_FLOAT_VN 4
+#define MODEL_FLOAT_CN 8
+#define MODEL_MAX_DEG 256
+static inline double stored(double x, int storage) {
+    storage &= 3;
+    if (storage == 1) return (double)(float)x;
+    if (storage == 2) return (double)(float)(x * 1.4426950408889634) * 0.6931471805599453;
+    return x;
+}
+
+static int decode_sparse_stored(const oracle_graph* g, const double* lambda, int max_iters, int early_term,
+                                int cn_rule, uint8_t* hard, int32_t* iters_out, int32_t* synd_out,
+                                double* alpha, double* beta, double* th, ulp_noise* nz, int storage) {
     const int m = g->m, n = g->n;
     const int64_t E = g->E;
     for (int64_t p = 0; p < E; p++) alpha[p] = 0.0; /* new double[numC][numV], :57 */
@@ -173,17 +192,60 @@ static int decode_sparse(const oracle_graph* g, const double* lambda, int max_it
         /* variable nodes, :67-79 */
         for (int j = 0; j < n; j++) {
             const int32_t a = g->col_ptr[j], b = g->col_ptr[j + 1];
+            if ((storage & MODEL_FLOAT_VN) && b - a <= MODEL_MAX_DEG && b > a) {
+                const float kb = 1.4426950408889634f, kn = 0.6931471805599453f;
+                float pre[MODEL_MAX_DEG + 1], al[MODEL_MAX_DEG];
+                const int d = b - a;
+                pre[0] = (float)(lambda[j] * (double)kb);
+                for (int k = 0; k < d; k++) {
+                    al[k] = (float)(alpha[g->col_edge[a + k]] * (double)kb);
+                    pre[k + 1] = pre[k] + al[k];
+                }
+                float suf = al[d - 1];
+                beta[g->col_edge[a + d - 1]] = (double)pre[d - 1] * (double)kn;
+                for (int k = d - 2; k >= 0; k--) {
+                    beta[g->col_edge[a + k]] = (double)(pre[k] + suf) * (double)kn;
+                    suf = al[k] + suf;
+                }
+                continue;
+            }
             for (int32_t x = a; x < b; x++) {
                 double s = lambda[j];
                 for (int32_t y = a; y < b; y++) {
                     if (y == x) continue;
                     s += alpha[g->col_edge[y]];
                 }
-                beta[g->col_edge[x]] = s;
+                beta[g->col_edge[x]] = stored(s, storage);
             }
         }
         /* check nodes, :82-95 (sum-product) or MinSumDecoder.java:76-94 */
-        if (cn_rule == ORACLE_CN_SUMPRODUCT) {
+        if (cn_rule == ORACLE_CN_SUMPRODUCT && (storage & MODEL_FLOAT_CN)) {
+            const double kb = 1.4426950408889634, kn = 0.6931471805599453;
+            for (int i = 0; i < m; i++) {
+                const int32_t a = g->row_ptr[i];
+                const int d = g->row_ptr[i + 1] - a;
+                if (d > MODEL_MAX_DEG) return -1;
+                float q[MODEL_MAX_DEG], pq[MODEL_MAX_DEG];
+                int sg[MODEL_MAX_DEG], all = 0;
+                float Q = 0.0f;
+                for (int k = 0; k < d; k++) {
+                    const float bb = (float)(beta[a + k] * kb);
+                    sg[k] = signbit(bb) ? 1 : 0;
+                    q[k] = (fabsf(bb) >= 55.0f) ? 0.0f : 1.0f / fmaf(exp2f(fabsf(bb)), 0.5f, 0.5f);
+                    if (isnan(bb)) q[k] = bb;
+                    pq[k] = Q;
+                    Q = (k == 0) ? q[k] : fmaf(q[k], 1.0f - Q, Q);
+                    all ^= sg[k];
+                }
+                float sQ = 0.0f;
+                for (int k = d - 1; k >= 0; k--) {
+                    const float QQ = (k == d - 1) ? pq[k] : (k == 0) ? sQ : fmaf(sQ, 1.0f - pq[k], pq[k]);
+                    const float mag = log2f(fmaf(1.0f / QQ, 2.0f, -1.0f));
+                    alpha[a + k] = (double)((all ^ sg[k]) ? -mag : mag) * kn;
+                    sQ = (k == d - 1) ? q[k] : fmaf(q[k], 1.0f - sQ, sQ);
+                }
+            }
+        } else if (cn_rule == ORACLE_CN_SUMPRODUCT) {
             for (int64_t p = 0; p < E; p++) th[p] = ref_tanh(0.5 * beta[p], nz);
             for (int i = 0; i < m; i++) {
                 const int32_t a = g->row_ptr[i], b = g->row_ptr[i + 1];
@@ -193,7 +255,7 @@ static int decode_sparse(const oracle_graph* g, const double* lambda, int max_it
                         if (y == x) continue;
                         prod *= th[y];
                     }
-                    alpha[x] = 2 * ref_atanh(prod, nz);
+                    alpha[x] = stored(2 * ref_atanh(prod, nz), storage);
                 }
             }
         } else {
@@ -208,14 +270,21 @@ static int decode_sparse(const oracle_graph* g, const double* lambda, int max_it
                     double mn = 1.7976931348623157e308; /* Double.MAX_VALUE */
                     for (int32_t y = a; y < b; y++)
                         if (y != x && mn > fabs(beta[y])) mn = fabs(beta[y]);
-                    alpha[x] = prod * mn * 0.7;
+                    alpha[x] = stored(prod * mn * 0.7, storage);
                 }
             }
         }
         /* tentative decision, :98-105 */
         for (int j = 0; j < n; j++) {
             double gsum = lambda[j];
-            for (int32_t y = g->col_ptr[j]; y < g->col_ptr[j + 1]; y++) gsum += alpha[g->col_edge[y]];
+            if (storage & MODEL_FLOAT_VN) {
+                float gf = (float)(lambda[j] * 1.4426950408889634);
+                for (int32_t y = g->col_ptr[j]; y < g->col_ptr[j + 1]; y++)
+                    gf += (float)(alpha[g->col_edge[y]] * 1.4426950408889634);
+                gsum = (double)gf;
+            } else {
+                for (int32_t y = g->col_ptr[j]; y < g->col_ptr[j + 1]; y++) gsum += alpha[g->col_edge[y]];
+            }
             hard[j] = (gsum < 0) ? 1 : 0;
         }
         /* parity check, :108-116, on the sparse rows */
@@ -234,6 +303,13 @@ static int decode_sparse(const oracle_graph* g, const double* lambda, int max_it
     *iters_out = max_iters; /* :122 */
     *synd_out = sum_syndro;
     return 0;
+}
+
+static int decode_sparse(const oracle_graph* g, const double* lambda, int max_iters, int early_term,
+                         int cn_rule, uint8_t* hard, int32_t* iters_out, int32_t* synd_out,
+                         double* alpha, double* beta, double* th, ulp_noise* nz) {
+    return decode_sparse_stored(g, lambda, max_iters, early_term, cn_rule, hard, iters_out, synd_out,
+                                alpha, beta, th, nz, 0);
 }
 
 int oracle_decode_llr(const oracle_graph* g, const double* llr, int max_iters, int early_term,
@@ -300,6 +376,35 @@ int oracle_decode_llr_batch_f32(const oracle_graph* g, const float* llr, int64_t
                 for (int j = 0; j < n; j++) lam[j] = (double)llr[f * n + j];
                 decode_sparse(g, lam, max_iters, early_term, cn_rule, hard + f * n, iters + f,
                               syndrome_weight + f, alpha, beta, th, NULL);
+            }
+        }
+        free(alpha); free(beta); free(th); free(lam);
+    }
+    return fail ? -2 : 0;
+}
+
+int oracle_decode_llr_batch_f32_stored(const oracle_graph* g, const float* llr, int64_t frames,
+                                       int max_iters, int early_term, int cn_rule, uint8_t* hard,
+                                       int32_t* iters, int32_t* syndrome_weight, int threads, int storage) {
+    const int n = g->n;
+    const int64_t E = g->E ? g->E : 1;
+    int fail = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        double* alpha = (double*)malloc((size_t)E * sizeof(double));
+        double* beta = (double*)calloc((size_t)E, sizeof(double));
+        double* th = (double*)malloc((size_t)E * sizeof(double));
+        double* lam = (double*)malloc((size_t)(n ? n : 1) * sizeof(double));
+        if (!alpha || !beta || !th || !lam) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+#pragma omp for schedule(dynamic, 4)
+            for (int64_t f = 0; f < frames; f++) {
+                for (int j = 0; j < n; j++) lam[j] = stored((double)llr[f * n + j], storage);
+                decode_sparse_stored(g, lam, max_iters, early_term, cn_rule, hard + f * n, iters + f,
+                                     syndrome_weight + f, alpha, beta, th, NULL, storage);
             }
         }
         free(alpha); free(beta); free(th); free(lam);

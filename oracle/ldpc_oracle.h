@@ -58,6 +58,14 @@ int oracle_decode_llr_batch_f32(const oracle_graph* g, const float* llr, int64_t
                                 int max_iters, int early_term, int cn_rule, uint8_t* hard,
                                 int32_t* iters, int32_t* syndrome_weight, int threads);
 
+/* The same batch with the messages (and LLRs) STORED as 4-byte floats while every operation stays
+ * double: storage 0 = double (the call above), 1 = each alpha / beta rounded to float when it is
+ * written, 2 = rounded to float in units of bits (x / ln 2).  Not the reference's arithmetic: it
+ * separates what float storage alone does to a decode from what float arithmetic does. */
+int oracle_decode_llr_batch_f32_stored(const oracle_graph* g, const float* llr, int64_t frames,
+                                       int max_iters, int early_term, int cn_rule, uint8_t* hard,
+                                       int32_t* iters, int32_t* syndrome_weight, int threads, int storage);
+
 /* Frame batch from double LLRs: what the reference itself decodes from in its BSC modes (lambda is a
  * double[] there, LogDecoder.java:45-54).  tanh_ulps / log_ulps > 0 move every tanh / log result by a
  * random whole number of ulps of at most that size (seeded per frame by noise_seed): the JDK specifies

@@ -37,6 +37,7 @@ def _load():
     lib.oracle_graph_csc.argtypes = [vp, vp, vp]
     lib.oracle_decode_llr.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.oracle_decode_llr_batch_f32.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, i32]
+    lib.oracle_decode_llr_batch_f32_stored.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, i32, i32]
     lib.oracle_decode_llr_batch_f64.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, i32, i32, i32, u64]
     lib.oracle_decode_llr_noisy.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, u64]
     lib.oracle_bsc_llr.argtypes = [i32, i32, vp, f64, i32, vp]
@@ -133,18 +134,20 @@ class Graph:
             raise RuntimeError("oracle_decode_llr_noisy failed: %d" % rc)
         return hard, it.value, sw.value, al[: self.E], be[: self.E]
 
-    def decode_llr_batch(self, llr, max_iters, early_term=True, cn_rule=CN_SUMPRODUCT, threads=None):
+    def decode_llr_batch(self, llr, max_iters, early_term=True, cn_rule=CN_SUMPRODUCT, threads=None, storage=0):
+        """storage 0: the reference's double messages.  1 / 2: every message rounded to a 4-byte float (in nats /
+        in bits) when it is stored, all operations still double -- what float storage alone does to a decode."""
         llr = np.ascontiguousarray(llr, dtype=np.float32)
         frames = llr.shape[0]
         assert llr.shape == (frames, self.n)
         hard = np.zeros((frames, self.n), np.uint8)
         it = np.zeros(frames, np.int32)
         sw = np.zeros(frames, np.int32)
-        rc = lib().oracle_decode_llr_batch_f32(self._h, _p(llr), frames, int(max_iters), int(bool(early_term)),
-                                               int(cn_rule), _p(hard), _p(it), _p(sw),
-                                               int(threads or max_threads()))
+        rc = lib().oracle_decode_llr_batch_f32_stored(self._h, _p(llr), frames, int(max_iters), int(bool(early_term)),
+                                                      int(cn_rule), _p(hard), _p(it), _p(sw),
+                                                      int(threads or max_threads()), int(storage))
         if rc != 0:
-            raise RuntimeError("oracle_decode_llr_batch_f32 failed: %d" % rc)
+            raise RuntimeError("oracle_decode_llr_batch_f32_stored failed: %d" % rc)
         return hard, it, sw
 
     def decode_llr_batch_f64(self, llr, max_iters, early_term=True, cn_rule=CN_SUMPRODUCT, threads=None,

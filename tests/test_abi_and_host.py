@@ -156,29 +156,61 @@ while done < 2000 and alone[1] < 12:
     alone += g.simulate(oc.CH_BSC_ALL, 0.04, 5, 40 + done, 150, 20, threads=1)
     done += 150
 assert (until == alone).all() and until[1] >= 12 and until[0] == done < 2000, (until[:3], alone[:3])
-assert len(calls) == done // 150 and all(c == 75 for _, c in calls)
+assert len(calls) == done // 150 and sum(c for _, c in calls) == L.sim.shard_range(0, 150, rank, world)[1] * (done // 150)
 capped = L.sim.simulate_until(fn, 20, min_frame_errors=10 ** 9, max_frames=260, batch=100, rank=rank, world=world)
 assert capped[0] == 260
+# the same point with the counters kept in a tensor (the stand-in for Decoder.simulate_dev adds into it): one
+# all-reduce of that tensor per batch, one word read back; same stop batch, same counters, for every world size
+import torch
+shares = []
+def acc(first, count, tensor):
+    shares.append((first, count))
+    tensor += torch.from_numpy(fn(first, count).astype(np.int64))
+on_dev = L.sim.simulate_until(None, 20, min_frame_errors=12, max_frames=2000, batch=150, first_frame=40, rank=rank,
+                              world=world, device="cpu", accumulate_fn=acc)
+assert on_dev.dtype == np.uint64 and (on_dev == alone).all(), (on_dev[:3], alone[:3])
+assert len(shares) == done // 150
+print("STOP", int(on_dev[0]), int(on_dev[1]))
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
 
 
-def test_world_size_two_gloo(tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT))
+def _run_gloo_workers(script, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
+    outs = []
     for p in procs:
         out, _ = p.communicate(timeout=240)
         assert p.returncode == 0, out
+        outs.append(out)
+    return outs
+
+
+def test_world_size_two_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    _run_gloo_workers(script, 2)
+
+
+def test_stop_batch_does_not_depend_on_the_number_of_ranks(tmp_path):
+    """The stop rule of an error-rate point (>= N frame errors, looked at once per batch of global frames) with 1, 2
+    and 3 ranks on gloo: every rank of every world size stops after the same batch with the same counters, on the
+    host-counter path and on the tensor path alike (the worker also checks both against an unsharded run)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    stops = set()
+    for world in (1, 2, 3):
+        for out in _run_gloo_workers(script, world):
+            stops.add([l for l in out.splitlines() if l.startswith("STOP")][0])
+    assert len(stops) == 1, stops
 
 
 def test_bench_plumbing_world_size_two_gloo():

@@ -163,3 +163,63 @@ def test_config3_stop_rule_on_the_gpu(pkg):
     assert clean[16:].sum() == clean[0] and noisy[16:].sum() == noisy[0]     # every frame is in the histogram
     r = pkg.sim.rates(noisy, m, n)
     assert 0.05 < r["FER"] <= 1.0 and r["avg_iters_wrong"] == L
+
+
+def test_config2_at_its_full_batch(pkg, oracle):
+    """The headline workload itself: 1,048,576 frames of the (3,6) n = 4096 code, AWGN at 1.0 dB, exactly 50
+    iterations, default engine, one call (the loop LogDecoder.java:64-120 for the whole batch; rows of the last
+    frames start beyond 2^32 bytes in the LLR array and beyond 2^32 in the hard-decision array).  The first
+    3,000 and the last 3,000 frames of the batch are decoded by the double oracle from the same LLRs: every frame
+    the oracle brings to a zero syndrome must come out with the same triple, and so must the frames it does not,
+    except for what 4-byte messages do to a frame that is still oscillating after 50 iterations (83 % of the
+    frames at this point never settle; the word such a frame holds at the end turns on the eighth digit of a
+    message: see test_hard_decision_agreement_at_scale_irregular) -- at most 1.5 x the count of the oracle's own
+    float model on the same frames + 3, iteration counts equal, every one itemised.  The reported syndrome
+    weight must be the weight of the reported word on a strided sample of 4,096 frames, and the frame error rate
+    of the whole batch must lie inside the 95 % interval of the oracle's 6,000 frames."""
+    import torch
+    m, n, rows, cols = pkg.codes.regular_ldpc(4096, 3, 6, seed=1)
+    dec = pkg.Decoder(m, n, rows, cols)
+    g = oracle.Graph(m, n, rows, cols)
+    F, L, S = 1 << 20, 50, 3000
+    d_llr = torch.empty((F, n), dtype=torch.float32, device="cuda")
+    d_hard = torch.empty((F, n), dtype=torch.uint8, device="cuda")
+    d_it = torch.empty(F, dtype=torch.int32, device="cuda")
+    d_sw = torch.empty(F, dtype=torch.int32, device="cuda")
+    dec.gen_awgn_llr_dev(1.0, 0x5EED, 0, F, d_llr.data_ptr())
+    dec.decode_batch_dev(d_llr.data_ptr(), F, L, False, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
+    torch.cuda.synchronize()
+    assert dec.last_decode_kernel() == "bp_lds_kernel"
+    assert (d_it == L).all()
+    failed = (d_hard != 0).any(dim=1)                # the all-zero word was sent
+    oracle_failed = gpu_differ = model_differ = 0
+    items, model_items = [], []
+    for lo in (0, F - S):
+        llr = d_llr[lo:lo + S].cpu().numpy()
+        want = g.decode_llr_batch(llr, L, False)
+        model = g.decode_llr_batch(llr, L, False, storage=14)
+        got = (d_hard[lo:lo + S].cpu().numpy(), d_it[lo:lo + S].cpu().numpy(), d_sw[lo:lo + S].cpu().numpy())
+        differ = np.nonzero(~((got[0] == want[0]).all(axis=1) & (got[1] == want[1]) & (got[2] == want[2])))[0]
+        items += [(lo + int(f), int((got[0][f] != want[0][f]).sum()), int(got[2][f]), int(want[2][f])) for f in differ]
+        assert (want[2][differ] > 0).all() and (got[2][differ] > 0).all(), items   # never a frame the oracle decodes
+        assert (got[1] == want[1]).all()
+        gpu_differ += differ.size
+        mdiff = np.nonzero(~((model[0] == want[0]).all(axis=1) & (model[2] == want[2])))[0]
+        model_differ += mdiff.size
+        model_items += [lo + int(f) for f in mdiff]
+        oracle_failed += int(want[0].any(axis=1).sum())
+        assert int(failed[lo:lo + S].sum()) == int(want[0].any(axis=1).sum())
+    print("first and last %d frames: %d undecoded frames hold another word than the double oracle's (its float model: %d); "
+          "(frame, bits, weight gpu / oracle): %s; frames of the float model: %s" % (S, gpu_differ, model_differ, items, model_items))
+    assert gpu_differ <= 1.5 * model_differ + 3, items
+    pick = torch.arange(0, F, F // 4096, device="cuda")
+    H = torch.zeros((m, n), dtype=torch.float32, device="cuda")
+    H[torch.from_numpy(rows).long().cuda(), torch.from_numpy(cols).long().cuda()] = 1
+    w = (d_hard[pick].float() @ H.T).remainder(2).sum(dim=1).int()
+    assert (w == d_sw[pick]).all()
+    assert (d_sw[~failed] == 0).all()                # the sent word has syndrome weight 0
+    fer = float(failed.float().mean())
+    lo, hi = _ci95(oracle_failed, 2 * S)
+    print("config 2 at 1,048,576 frames: FER %.5f, oracle %d of %d failed, 95 %% interval [%.4f, %.4f]" % (fer, oracle_failed, 2 * S, lo, hi))
+    assert lo <= fer <= hi
+    dec.close()

@@ -58,3 +58,62 @@ def test_load_int_stream(pkg, tmp_path):
     assert sum(int(l.split(",")[1]) for l in lines[8:8 + 15]) == 300 == cnt[0][0]
     with pytest.raises(FileNotFoundError):
         pkg.drivers.load_int_stream("missing", 8, 2, out_dir=str(tmp_path))
+
+
+def test_the_java_stubs_call_sequence_through_the_c_abi(tmp_path, pkg):
+    """host/stub_sequence.c makes the native calls of the Java binding of LogDecoder.decode in its
+    order: contexts in a least-recently-used cache of four (a fifth matrix destroys the oldest), page-locked
+    frame buffers allocated once and reused, ldpc_amd_decode_bsc_batch per batch (LogDecoder.java:15-17, callers
+    LDPC_GallagerIntStreamSimu.java:55-76, :122).  Every call's outputs must equal the same call through the
+    Python binding on a fresh context, and every context created must have been destroyed."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg_dir = os.path.join(root, "ldpc-simulator_amd")
+    exe = tmp_path / "stub_sequence"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", os.path.join(pkg_dir, "host", "stub_sequence.c"),
+                    "-I", os.path.join(root, "include"), "-L", pkg_dir, "-lldpc_amd", "-Wl,-rpath," + pkg_dir, "-o", str(exe)],
+                   check=True, capture_output=True, text=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1] == "contexts created 8 destroyed 8 buffer allocations 4", lines[-1]
+
+    mask64 = (1 << 64) - 1
+
+    class Lcg:
+        def __init__(self, seed):
+            self.s = seed
+        def next(self):
+            self.s = (self.s * 6364136223846793005 + 1442695040888963407) & mask64
+            return self.s >> 33
+
+    def matrix(n, seed):
+        g = Lcg(seed)
+        perm = list(range(n))
+        for j in range(n - 1, 0, -1):
+            k = g.next() % (j + 1)
+            perm[j], perm[k] = perm[k], perm[j]
+        m2 = n // 8
+        rows = [i for i in range(m2) for _ in range(8)] + [m2 + i for i in range(m2) for _ in range(8)]
+        cols = [8 * i + k for i in range(m2) for k in range(8)] + [perm[8 * i + k] for i in range(m2) for k in range(8)]
+        return np.array(rows, np.int32), np.array(cols, np.int32)
+
+    n = 1024
+    order = [0, 1, 0, 2, 3, 1, 4, 0, 5, 4, 2]
+    frames_of = [64, 200, 1, 200, 333, 64, 200, 17, 1000, 200, 64]
+    for call, (k, F) in enumerate(zip(order, frames_of)):
+        rows, cols = matrix(n, 1000 + k)
+        dec = pkg.Decoder(n // 4, n, rows, cols)
+        g = Lcg(77 + call)
+        rx = np.zeros(F * n, np.uint8)
+        for t in range(F * n):
+            if t % n < n - n // 4:
+                rx[t] = 1 if g.next() % 1000 < 20 else 0
+        hard, it, sw = dec.decode_bsc_batch(rx.reshape(F, n), 0.02, 50, pkg.capi.LLR_PARITY_LN1E20, True)
+        h = 1469598103934665603
+        for v in hard.reshape(-1).tolist():
+            h = ((h ^ v) * 1099511628211) & mask64
+        want = "call %d matrix %d frames %d checksum %d iters %d weight %d" % (call, k, F, h, int(it.sum()), int(sw.sum()))
+        assert lines[call] == want, (lines[call], want)
+        dec.close()

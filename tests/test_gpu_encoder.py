@@ -182,3 +182,17 @@ def test_accounting_inside_the_resident_kernels_equals_the_counting_pass(pkg, or
         dec.set_option("sim_fused", 0)
         assert (a == dec.simulate(oracle.CH_BSC_INFO, 0.03, 17, 0, 300, 10, True)).all()
         dec.close()
+
+
+def test_generator_larger_than_the_codeword_kernel_takes_is_refused_at_once(pkg):
+    """The codeword kernel keeps the message bits of 64 frames in LDS: k above LDPC_AMD_MAX_GENERATOR_ROWS is refused
+    by ldpc_amd_set_generator itself, not in the middle of a leg."""
+    n, k = 10400, 10177
+    dec = pkg.Decoder(n - k, n, np.arange(n - k, dtype=np.int32), np.arange(n - k, dtype=np.int32))
+    with pytest.raises(pkg.capi.LdpcError) as err:
+        dec.set_generator(np.zeros((k, n), np.uint8))
+    assert err.value.code == pkg.capi.ELIMIT
+    dec.set_generator(np.zeros((k - 1, n), np.uint8))        # the limit itself is accepted
+    c = dec.simulate(pkg.capi.CH_BSC_ALL, 0.01, 1, 0, 64, 2, True)
+    assert c[0] == 64
+    dec.close()

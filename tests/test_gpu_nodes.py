@@ -24,6 +24,14 @@ def _both(dec, call):
     dec.set_option("nodes", 1)
     a = call()
     assert dec.last_decode_kernel() == "bp_nodes_kernel"
+    # the one-level grid barrier instead of the per-XCD one: a difference would mean that one of them lets a
+    # workgroup read messages another has not made visible yet
+    dec.set_option("nodes_flat_barrier", 1)
+    flat = call()
+    assert dec.last_decode_kernel() == "bp_nodes_kernel"
+    dec.set_option("nodes_flat_barrier", 0)
+    for x, y in zip(a, flat):
+        assert (x == y).all(), "the two grid barriers of bp_nodes_kernel return different bits"
     dec.set_option("nodes", 0)
     b = call()
     assert dec.last_decode_kernel() == "rows_cn_kernel"
@@ -116,6 +124,46 @@ def test_refused_cooperative_launch_is_observable_and_not_final(pkg):
     assert dec.last_decode_kernel() == "bp_nodes_kernel"         # one refusal does not disable the engine
     for x, y in zip(again, want):
         assert (x == y).all()
+    dec.close()
+
+
+def test_a_grid_barrier_that_gave_up_is_an_error_everywhere(pkg, oracle):
+    """bp_nodes_kernel's grid barriers are bounded waits; one that gives up leaves meaningless results.  With the
+    time-out flag raised before the launch (test option), every path must say so: the host-pointer decode and a
+    Monte-Carlo leg fail, and a caller of the device-pointer entry point finds -1 in every iteration count and
+    syndrome weight and 1 in the read-only option after synchronising.  Without the flag the same calls succeed."""
+    import torch
+    _, (m, n, rows, cols) = pkg.codes.nr_bg1_shaped(z=8, seed=3)
+    dec = pkg.Decoder(m, n, rows, cols)
+    dec.set_option("generic_lds_kb", -1)
+    dec.set_option("nodes", 1)
+    F, L = 6, 10
+    llr = oracle.gen_awgn_llr(m, n, 2.0, seed=3, first_frame=0, frames=F)
+    good = dec.decode_batch(llr, L, True)
+    assert dec.last_decode_kernel() == "bp_nodes_kernel" and dec.get_option("nodes_barrier_timed_out") == 0
+    d_llr = torch.from_numpy(llr).cuda()
+    d_hard = torch.empty((F, n), dtype=torch.uint8, device="cuda")
+    d_it = torch.zeros(F, dtype=torch.int32, device="cuda")
+    d_sw = torch.zeros(F, dtype=torch.int32, device="cuda")
+    dec.set_option("test_nodes_timeout", 1)
+    with pytest.raises(pkg.capi.LdpcError) as err:
+        dec.decode_batch(llr, L, True)
+    assert err.value.code == pkg.capi.EHIP and "barrier" in str(err.value)
+    dec.decode_batch_dev(d_llr.data_ptr(), F, L, True, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
+    torch.cuda.synchronize()
+    assert dec.last_decode_kernel() == "bp_nodes_kernel"
+    assert dec.get_option("nodes_barrier_timed_out") == 1
+    assert (d_it.cpu().numpy() == -1).all() and (d_sw.cpu().numpy() == -1).all()
+    with pytest.raises(pkg.capi.LdpcError) as err:
+        dec.simulate(pkg.capi.CH_AWGN, 2.0, 1, 0, F, L, True)
+    assert err.value.code == pkg.capi.EHIP
+    dec.set_option("test_nodes_timeout", 0)
+    dec.decode_batch_dev(d_llr.data_ptr(), F, L, True, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
+    torch.cuda.synchronize()
+    assert dec.get_option("nodes_barrier_timed_out") == 0
+    assert (d_hard.cpu().numpy() == good[0]).all() and (d_it.cpu().numpy() == good[1]).all() and (d_sw.cpu().numpy() == good[2]).all()
+    c = dec.simulate(pkg.capi.CH_AWGN, 2.0, 1, 0, F, L, True)
+    assert c[0] == F
     dec.close()
 
 

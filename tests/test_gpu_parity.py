@@ -424,31 +424,47 @@ def test_hard_decision_agreement_at_scale(c1, c2, oracle, engine):
     assert triple_bad <= MAX_DIFFERING(total), notes
 
 
-def test_hard_decision_agreement_at_scale_irregular(pkg, oracle, engine):
-    """The engines an irregular code runs on (generic frame-resident kernel, row-parallel sweeps; degrees
-    3..19 / 1..30) on 20,000 + 12,000 frames.  Measured here and enforced:
-      * every frame the double oracle decodes (zero syndrome) comes out of the GPU with the same word, the
-        same iteration count and syndrome 0 -- no differing frame;
-      * of the frames the oracle does NOT decode in 50 iterations (0.3 % at 2 dB, 17 % at 1 dB) the GPU does
-        not decode any either and reports 50 iterations, but for about 1 % of THEM (0.1 % of all frames) the
-        word it holds after the 50th iteration differs from the oracle's in 1 - 5 of 1088 positions: the
-        messages of such a frame keep oscillating, posteriors pass through zero, and an fp32 rounding error
-        (1e-7 relative, the double reference: 1e-16) decides a sign.  This is the fp32-vs-double divergence of
-        this path; it does not occur on frames that converge, and it did not occur at all on the regular
-        codes (64,000 frames, test above).  Bound enforced: at most 2e-3 of all frames, none outside the
-        undecoded ones, every one itemised in the output."""
-    if engine not in ("resident_generic", "stream_rows"):
-        pytest.skip("the two engines that decode irregular codes by default")
+@pytest.fixture(scope="module")
+def irregular_at_scale(pkg, oracle):
+    """NR-BG1-shaped Z = 16 code, 20,000 + 12,000 frames, decoded once by the double oracle and by the same oracle
+    with parts switched to float (oracle/ldpc_oracle.c `stored`): storage 2 = every message rounded to a 4-byte
+    float when it is written, all arithmetic double; 14 = that plus the variable-node sums and the check-node rule
+    on complements in float, in the association the kernels use - a model of the float implementation."""
     _, (m, n, rows, cols) = pkg.codes.nr_bg1_shaped(z=16, seed=4)
-    dec = pkg.Decoder(m, n, rows, cols)
     g = oracle.Graph(m, n, rows, cols)
-    total = decoded = decoded_bad = undecoded = undecoded_bad = 0
-    notes = []
+    cases = []
     for ebn0, F in ((2.0, 20000), (1.0, 12000)):
         llr = oracle.gen_awgn_llr(m, n, ebn0, seed=33, first_frame=0, frames=F)
+        want = g.decode_llr_batch(llr, 50, True)
+        others = {mode: _agreement(g.decode_llr_batch(llr, 50, True, storage=mode), want)[1] for mode in (2, 14)}
+        cases.append((ebn0, F, llr, want, others))
+    return dict(m=m, n=n, rows=rows, cols=cols, cases=cases)
+
+
+def test_hard_decision_agreement_at_scale_irregular(pkg, oracle, engine, irregular_at_scale):
+    """The engines an irregular code runs on (generic frame-resident kernel, row-parallel sweeps; degrees
+    3..19 / 1..30) on 20,000 + 12,000 frames.  Enforced:
+      * every frame the double oracle decodes (zero syndrome) comes out of the GPU with the same word, the
+        same iteration count and syndrome 0 -- no differing frame;
+      * a frame the oracle does NOT decode in 50 iterations (0.3 % at 2 dB, 17 % at 1 dB) is not decoded by the
+        GPU either and reports 50 iterations.  The word such a frame holds after the 50th iteration is not a
+        stable quantity: its messages keep oscillating, posteriors pass through zero, and the eighth digit of a
+        message decides a sign.  The double oracle itself, with nothing changed but its messages rounded to
+        4-byte floats when they are stored (all arithmetic still double), returns a different word for 12 of
+        these 32,000 frames -- more than the 1e-4 bar allows, so no implementation with 4-byte messages can
+        meet that bar on this code; with the float arithmetic of the kernels modelled as well it is 29, and the
+        GPU itself differs on 31 (tools/fp32_storage_study.py).  So the GPU is held to what its number format
+        allows: among the undecoded frames at most 1.5 x the count of the float model of the oracle (+ 3), none
+        among the decoded ones, every one itemised."""
+    if engine not in ("resident_generic", "stream_rows"):
+        pytest.skip("the two engines that decode irregular codes by default")
+    c = irregular_at_scale
+    dec = pkg.Decoder(c["m"], c["n"], c["rows"], c["cols"])
+    total = decoded = decoded_bad = undecoded = undecoded_bad = model_bad = storage_bad = shared = 0
+    notes = []
+    for ebn0, F, llr, want, others in c["cases"]:
         got = dec.decode_batch(llr, 50, True)
         assert dec.last_decode_kernel() == {"resident_generic": "bp_lds_gen_kernel", "stream_rows": "rows_cn_kernel"}[engine]
-        want = g.decode_llr_batch(llr, 50, True)
         _, td = _agreement(got, want)
         conv = want[2] == 0
         total += F
@@ -456,14 +472,21 @@ def test_hard_decision_agreement_at_scale_irregular(pkg, oracle, engine):
         undecoded += int((~conv).sum())
         decoded_bad += int(conv[td].sum())
         undecoded_bad += int((~conv[td]).sum())
+        assert not conv[others[2]].any() and not conv[others[14]].any()     # the float variants of the oracle: undecoded frames only
+        storage_bad += others[2].size
+        model_bad += others[14].size
+        shared += np.intersect1d(td, np.union1d(others[2], others[14])).size
         # an undecoded frame is undecoded on both sides, after all 50 iterations on both sides
         assert ((got[2] > 0) == ~conv).all() and (got[1][~conv] == 50).all() and (want[1][~conv] == 50).all()
         notes.append((ebn0, F, int((~conv).sum()), td.size, _itemise(got, want, td, limit=40)))
     print("%s, irregular n=%d: %d frames; of %d the oracle decodes %d differ; of %d it does not decode %d hold a "
-          "different word after iteration 50; per case (dB, frames, undecoded, differing, items = (frame, bits, iters "
-          "gpu/oracle, syndrome weight gpu/oracle)): %s" % (engine, n, total, decoded, decoded_bad, undecoded, undecoded_bad, notes))
-    assert decoded_bad <= MAX_DIFFERING(decoded), notes
-    assert undecoded_bad <= 2e-3 * total, notes
+          "different word after iteration 50 (the oracle with float storage alone: %d, with the float model of the "
+          "kernels' arithmetic: %d; %d of the GPU's frames are among those); per case (dB, frames, undecoded, differing, "
+          "items = (frame, bits, iters gpu/oracle, syndrome weight gpu/oracle)): %s"
+          % (engine, c["n"], total, decoded, decoded_bad, undecoded, undecoded_bad, storage_bad, model_bad, shared, notes))
+    assert decoded_bad == 0, notes
+    assert storage_bad > MAX_DIFFERING(total)          # float storage alone misses the bar: the divergence is in the format
+    assert undecoded_bad <= 1.5 * model_bad + 3, notes
     dec.close()
 
 

@@ -117,3 +117,35 @@ def test_awgn_sample_sensitivity_to_ulp_noise(oracle, pkg):
     # observed: 0 (also among the frames that never converge, whose messages settle on a fixed point that is
     # not a codeword); the bar leaves room for one frame in a thousand
     assert hard == 0 and changed <= tot * 1e-3
+
+
+def test_float_storage_and_float_model_of_the_oracle():
+    """The oracle's float variants (tools/fp32_storage_study.py, test_hard_decision_agreement_at_scale_irregular):
+    messages rounded to 4-byte floats when stored (1: nats, 2: bits), variable-node sums in float (+4), check-node
+    rule on complements in float (+8).  They are perturbations of the eighth digit: on frames that converge they
+    return the double decode's word (iteration counts may move by one on a handful), they keep the special values
+    (a saturated neighbourhood still gives +Inf, a NaN posterior still decodes to 0), and storage 0 is the double
+    decode itself."""
+    import ldpc_simulator_amd as L
+    from oracle import oracle_capi as oc
+    m, n, rows, cols = L.codes.regular_ldpc(768, 3, 6, seed=3)
+    g = oc.Graph(m, n, rows, cols)
+    llr = oc.gen_awgn_llr(m, n, 2.6, seed=12, first_frame=0, frames=600)
+    want = g.decode_llr_batch(llr, 40, True)
+    conv = want[2] == 0
+    assert conv.sum() > 500
+    same0 = g.decode_llr_batch(llr, 40, True, storage=0)
+    assert all((a == b).all() for a, b in zip(same0, want))
+    for mode in (1, 2, 6, 10, 14):
+        got = g.decode_llr_batch(llr, 40, True, storage=mode)
+        assert (got[0][conv] == want[0][conv]).all(), mode
+        assert (got[2][conv] == 0).all() and (np.abs(got[1][conv] - want[1][conv]) <= 1).all(), mode
+        assert (got[1][conv] != want[1][conv]).sum() <= 3, mode
+    # H = [[1 1 0], [1 0 1]], parity LLRs of ln 1e20: +Inf and -Inf meet in v0, NaN decodes to 0 (LogDecoder.java:93, :104)
+    g2 = oc.Graph(2, 3, [0, 0, 1, 1], [0, 1, 0, 2])
+    lam = oc.bsc_llr(2, 3, np.array([1, 0, 1], np.uint8), 0.1, oc.LLR_PARITY_LN1E20).astype(np.float32)[None, :]
+    ref = g2.decode_llr_batch(lam, 3, True)
+    for mode in (1, 2, 6, 10, 14):
+        got = g2.decode_llr_batch(lam, 3, True, storage=mode)
+        assert all((a == b).all() for a, b in zip(got, ref)), mode
+    assert ref[0][0][0] == 0

@@ -88,7 +88,8 @@ def fuzz(cases, seed):
         for name, env in (("default", {}), ("generic", {"engine": "generic"}),
                           ("sweeps, leaves touched", {"engine": "stream", "stream_kernel": 0, "rows_leaves": 0}),
                           ("one-launch", {"engine": "stream", "stream_kernel": 1}),
-                          ("nodes", {"generic_lds_kb": -1, "engine": "generic", "nodes": 1})):
+                          ("nodes", {"generic_lds_kb": -1, "engine": "generic", "nodes": 1}),
+                          ("nodes, one-level barrier", {"generic_lds_kb": -1, "engine": "generic", "nodes": 1, "nodes_flat_barrier": 1})):
             out, kernel = run(dec, call, env)
             seen[kernel] = seen.get(kernel, 0) + 1
             same = all(bool((a == b).all()) for a, b in zip(out, ref))

@@ -5,7 +5,7 @@ until at least 100 frames have failed or the frame budget (1e8 by default, the b
 1e-6) is spent.  It is the loop over error rates of LDPC_GallagerIntStreamSimu.java:79-213 with the
 stop rule in place of the fixed numFrames.
 
-    python tools/run_c3_sweep.py [--budget 100000000] [--out profiles/r02/c3_sweep]
+    python tools/run_c3_sweep.py [--budget 100000000] [--out profiles/r03/c3_sweep]
 
 With more than one GPU launch one rank per GPU (python -m torch.distributed.run --nproc-per-node N ...):
 frames shard by global index, the counters are all-reduced after every batch, the table does not depend
@@ -37,12 +37,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--budget", type=int, default=10 ** 8)
     ap.add_argument("--min-errors", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=1 << 20, help="frames per batch over all ranks")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per batch over all ranks (0 = 2^20 per rank, so that a rank's share of a batch does not shrink "
+                         "as ranks are added; the stop rule is looked at once per batch, so the frames a point runs depend on it)")
+    ap.add_argument("--host-counters", action="store_true",
+                    help="the counters of every batch through the host (ldpc_amd_simulate) instead of staying on the device")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--points", default="0,0.5,1,1.5,2,2.5,3,3.5,4")
     ap.add_argument("--seed", type=int, default=0x5EED)
     ap.add_argument("--zero-codeword", action="store_true", help="send the all-zero word instead of u * encodedG")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02", "c3_sweep"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03", "c3_sweep"))
     args = ap.parse_args()
 
     import torch
@@ -68,13 +72,16 @@ def main():
         dec = L.Decoder(m, n, r2.astype(np.int32), c2.astype(np.int32), device=local_rank)
         dec.set_generator(eg)
     k = n - m
+    batch = args.batch or world << 20
     table = []
     for ebn0 in [float(x) for x in args.points.split(",")]:
         fn = lambda first, count: dec.simulate(L.capi.CH_AWGN, ebn0, args.seed, first, count, args.iters, True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        # the counters stay on the device: one in-place all-reduce and one word read back per batch
+        acc = None if args.host_counters else L.sim.device_accumulator(dec, L.capi.CH_AWGN, ebn0, args.seed, args.iters, True)
         c = L.sim.simulate_until(fn, args.iters, min_frame_errors=args.min_errors, max_frames=args.budget,
-                                 batch=args.batch, rank=rank, world=world, device=dev)
+                                 batch=batch, rank=rank, world=world, device=dev, accumulate_fn=acc)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         r = L.sim.rates(c, m, n)
@@ -98,13 +105,13 @@ def main():
         meta = {"code": "regular (3,6) n=4096, seed 1" + ("" if args.zero_codeword else ", column-permuted for the systematic generator"),
                 "codewords": "all-zero" if args.zero_codeword else "random, u * encodedG (Philox stream 2)",
                 "max_iters": args.iters, "early_termination": True, "stop_rule": ">= %d frame errors or %d frames" % (args.min_errors, args.budget),
-                "batch": args.batch, "gpus": world, "seed": args.seed, "device": torch.cuda.get_device_name(local_rank)}
+                "batch": batch, "gpus": world, "seed": args.seed, "device": torch.cuda.get_device_name(local_rank)}
         with open(args.out + ".json", "w") as f:
             json.dump({"meta": meta, "points": table}, f, indent=1)
         with open(args.out + ".md", "w") as f:
             f.write("# Eb/N0 sweep, (3,6) n = 4096, early termination, <= %d iterations, %s codewords, %d GPU(s)\n\n" %
                     (args.iters, meta["codewords"].split(",")[0], world))
-            f.write("Stop rule per point: %s; batches of %d frames.  `%s`\n\n" % (meta["stop_rule"], args.batch, " ".join(sys.argv)))
+            f.write("Stop rule per point: %s; batches of %d frames.  `%s`\n\n" % (meta["stop_rule"], batch, " ".join(sys.argv)))
             f.write("| Eb/N0 dB | frames | frame errors | FER | 95 % interval | IBER | undetected | mean iterations | wall s | M frames/s | info Gbit/s | stopped by |\n")
             f.write("|---|---|---|---|---|---|---|---|---|---|---|---|\n")
             for r in table:
