@@ -311,6 +311,8 @@ def main(argv=None):
                     help="auto: frame-resident kernel when the code fits in LDS; stream: force the frame-major HBM kernel")
     ap.add_argument("--no-stream-leg", action="store_true",
                     help="skip the extra single-step measurement of the streaming engine (N=1 only)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="a decoder option for A/B measurements (ldpc_amd_set_option), e.g. --opt lds_frames=2")
     ap.add_argument("--no-config-legs", action="store_true",
                     help="skip the short measurements of the other configurations (C1, C4, C5; N=1 only)")
     ap.add_argument("--plumbing-test", action="store_true",
@@ -364,6 +366,9 @@ def main(argv=None):
         dec = L.Decoder(m, n, rows, cols, device=local_rank)
         if args.engine == "stream":
             dec.set_option("engine", "stream")
+        for kv in args.opt:
+            name, value = kv.split("=", 1)
+            dec.set_option(name, int(value))
         stream = torch.cuda.current_stream().cuda_stream
 
     def buf(shape, dtype):

@@ -187,7 +187,7 @@ def test_accounting_inside_the_resident_kernels_equals_the_counting_pass(pkg, or
 def test_generator_larger_than_the_codeword_kernel_takes_is_refused_at_once(pkg):
     """The codeword kernel keeps the message bits of 64 frames in LDS: k above LDPC_AMD_MAX_GENERATOR_ROWS is refused
     by ldpc_amd_set_generator itself, not in the middle of a leg."""
-    n, k = 10400, 10177
+    n, k = 10400, 10209
     dec = pkg.Decoder(n - k, n, np.arange(n - k, dtype=np.int32), np.arange(n - k, dtype=np.int32))
     with pytest.raises(pkg.capi.LdpcError) as err:
         dec.set_generator(np.zeros((k, n), np.uint8))

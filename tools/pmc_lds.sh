@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --cpu-seconds 0 --no-stream-leg ${PMC_FRAMES:+--frames $PMC_FRAMES} $*"
+ARGS="--steps 1 --warmup 0 --cpu-seconds 0 --no-stream-leg --no-config-legs ${PMC_FRAMES:+--frames $PMC_FRAMES} $*"
 i=0
 for GROUP in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
              "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS SQ_WAVES SQ_INSTS_SMEM" \
