@@ -153,9 +153,6 @@ int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
 #define LDPC_AMD_OPT_TUNE_NODES_FLAT_BARRIER 114 /* node-parallel kernel: 1 = every grid barrier is the one-level one (each workgroup
                                                 releases and arrives at one counter); 0 (default) = workgroups meet per XCD first.
                                                 Same results; the A/B also checks the two-level barrier's visibility assumptions */
-#define LDPC_AMD_OPT_TUNE_LDS_FRAMES 115      /* frame-resident (6,3) kernels at fixed iterations: 2 = one workgroup holds two frames half an
-                                                iteration apart ("bp_lds2_kernel": one barrier per frame-iteration, one workgroup per CU; 4
-                                                variables per thread, 8 with LDPC_AMD_OPT_TUNE_LDS_VPT = 8); 0 / 1 = one frame per workgroup */
 #define LDPC_AMD_OPT_TEST_NODES_OVERSIZE 190 /* tests: ask for a cooperative grid the runtime must refuse */
 #define LDPC_AMD_OPT_TEST_NODES_TIMEOUT 191  /* tests: start the node-parallel kernel with its barrier time-out flag raised */
 /* read-only */

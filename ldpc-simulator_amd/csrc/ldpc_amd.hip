@@ -16,7 +16,6 @@
 
 #include "bp_kernels.hpp"
 #include "bp_lds.hpp"
-#include "bp_lds2.hpp"
 #include "bp_lds_gen.hpp"
 #include "bp_nodes.hpp"
 #include "bp_rows.hpp"
@@ -35,7 +34,7 @@ struct Options {
     int sim_chunk_mb = 2048;
     int verbose = 0;
     int lds_wpe = 0, lds_fpw = 0, generic_lds_kb = 0, nodes_blocks = 0, fpl = 0, layout = 0, rows_waves = 0, wps = 0,
-        nopipe = 0, rows_fused = -1, generic_threads = 0, lds_vpt = 0, lds_frames = 0;
+        nopipe = 0, rows_fused = -1, generic_threads = 0, lds_vpt = 0;
     int test_nodes_oversize = 0, test_nodes_timeout = 0, nodes_flat = 0;
 };
 
@@ -630,37 +629,6 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
                    (n2 == n || m2 - c->m >= dvr) &&
                    m2 <= 2048;  // the convergence test reads the syndrome words with one wavefront
         if (c->opt.engine != LDPC_AMD_ENGINE_AUTO) use = false;
-        // Two frames per workgroup, half an iteration apart (bp_lds2.hpp): fixed iterations, (6,3) codes, default rule,
-        // no accounting inside the kernel; 4 variables per thread (8 with lds_vpt = 8), one workgroup per CU.
-        if (use && c->opt.lds_frames == 2 && !early && dcr == 6 && !counting && c->cn_rule == LDPC_AMD_CN_SUMPRODUCT) {
-            const int vpt2 = c->opt.lds_vpt == 8 ? 8 : 4;
-            const int nt2 = (int)(((long long)n + vpt2 * 64 - 1) / (vpt2 * 64)) * 64;
-            const long long n22 = (long long)vpt2 * nt2, m22 = n22 * dvr / dcr;
-            const size_t msg_words2 = (size_t)(m22 / 2) * (size_t)lds_pair_stride(dcr);
-            const size_t lds2 = 2 * (size_t)lds2_frame_bytes((int)msg_words2, (int)(n22 / 32), (int)m22);
-            if (nt2 <= 4096 / vpt2 && lds2 <= 160 * 1024 && m22 % 32 == 0 && (n22 == n || m22 - c->m >= dvr)) {
-                if (int rc = build_resident_tables(c, nt2, vpt2)) return rc;
-                LdsParams q{};
-                q.m = (int)m22; q.n = n; q.nw = (int)(n22 / 32); q.E = n22 * dvr; q.msg_words = (int)msg_words2;
-                q.perm = c->d_res; q.pos_of_var = q.perm + n22; q.vn_off = q.pos_of_var + n22;
-                q.llr = src.kind == Src::Float ? src.llr : nullptr;
-                q.r = src.kind == Src::Bsc ? src.r : nullptr;
-                q.l0 = (float)(src.l0 * llr_scale(c)); q.l1 = (float)(src.l1 * llr_scale(c)); q.g_length = n - c->m;
-                q.scale = (float)llr_scale(c);
-                q.frames = frames; q.max_iters = max_iters;
-                q.hard = d_hard; q.out_iters = d_iters; q.out_synd = d_synd;
-                LdsLaunch l{};
-                l.rule = kCnComplement; l.early = false; l.frames_per_wg = 2; l.wpe = 0; l.vpt = vpt2; l.count = false;
-                l.threads = nt2; l.lds_bytes = lds2; l.stream = s;
-                LDPC_HIP(c, hipEventRecord(c->ev[0], s));
-                LDPC_HIP(c, bp_lds2_launch_6_3(l, q));
-                LDPC_HIP(c, hipEventRecord(c->ev[1], s));
-                c->timed_launches = 1;
-                c->timed_frames = frames;
-                c->last_kernel = "bp_lds2_kernel";
-                return LDPC_AMD_OK;
-            }
-        }
         if (use) {
             if (int rc = build_resident_tables(c, nt, vpt)) return rc;
             LdsParams q{};
@@ -1165,7 +1133,7 @@ int ldpc_amd_create(int32_t m, int32_t n, int64_t nnz, const int32_t* row_idx, c
     if (bp_generic_params_bytes() != sizeof(BpParams) || bp_6_3_params_bytes() != sizeof(BpParams) ||
         bp_8_2_params_bytes() != sizeof(BpParams) || bp_lds_6_3_params_bytes() != sizeof(LdsParams) ||
         bp_lds_8_2_params_bytes() != sizeof(LdsParams) || bp_lds_8_4_params_bytes() != sizeof(LdsParams) ||
-        bp_lds_10_5_params_bytes() != sizeof(LdsParams) || bp_lds2_6_3_params_bytes() != sizeof(LdsParams) || bp_lds_gen_params_bytes() != sizeof(LdsGenParams) ||
+        bp_lds_10_5_params_bytes() != sizeof(LdsParams) || bp_lds_gen_params_bytes() != sizeof(LdsGenParams) ||
         bp_rows_params_bytes() != sizeof(RowsParams) || bp_nodes_params_bytes() != sizeof(NodesParams))
         return fail(nullptr, LDPC_AMD_EHIP, "create: the library was linked from objects built against different headers");
     int ndev = 0;
@@ -1330,7 +1298,6 @@ int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
         case LDPC_AMD_OPT_TUNE_ROWS_LEAVES: if (!range(0, 1)) break; o.rows_leaves = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_SIM_CHUNK_MB: if (!range(16, 65536)) break; o.sim_chunk_mb = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_LDS_VPT: if (!(value == 0 || value == 8 || value == 12 || value == 16)) break; o.lds_vpt = v; return LDPC_AMD_OK;
-        case LDPC_AMD_OPT_TUNE_LDS_FRAMES: if (!(value == 0 || value == 1 || value == 2)) break; o.lds_frames = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: if (!(value == 0 || (value >= 64 && value <= 512 && value % 64 == 0))) break; o.generic_threads = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: if (!range(0, 1)) break; o.test_nodes_oversize = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TEST_NODES_TIMEOUT: if (!range(0, 1)) break; o.test_nodes_timeout = v; return LDPC_AMD_OK;
@@ -1369,7 +1336,6 @@ int ldpc_amd_get_option(const ldpc_amd_ctx* c, int32_t key, int64_t* value) {
         case LDPC_AMD_OPT_TUNE_SIM_CHUNK_MB: *value = o.sim_chunk_mb; break;
         case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: *value = o.generic_threads; break;
         case LDPC_AMD_OPT_TUNE_LDS_VPT: *value = o.lds_vpt; break;
-        case LDPC_AMD_OPT_TUNE_LDS_FRAMES: *value = o.lds_frames; break;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: *value = o.test_nodes_oversize; break;
         case LDPC_AMD_OPT_TEST_NODES_TIMEOUT: *value = o.test_nodes_timeout; break;
         case LDPC_AMD_OPT_TUNE_NODES_FLAT_BARRIER: *value = o.nodes_flat; break;
