@@ -85,7 +85,19 @@ struct LdsNo { static constexpr bool value = false; };
 // per CU) or 4 (128 registers, two).  VPT = 16: 3 (168 registers, three 4-wave workgroups per CU at n = 4096).
 // VPT = 12: 4 (103 registers).
 // COUNT: error accounting in place of the outputs (LdsParams::counters; LDPC_GallagerIntStreamSimu.java:136-183).
-template <int DC, int DV, int RULE, bool EARLY, int VPT, int WPE, bool COUNT = false>
+//
+// DEF: codes that are one edge short of regular in places (checks of degree DC or DC - 1, variables of degree DV or
+// DV - 1, as many short checks as short variables: a quasi-cyclic code with an empty block in its base matrix,
+// GenerateMatrix.java:100).  The host completes the graph with one extra edge per short node, from a short
+// variable to a short check, and marks it in the slot table (bit 0 of the variable's last slot offset).  The
+// extra edge carries constants that leave both nodes' arithmetic exactly as the reference's shorter loops have
+// it: the check reads +Inf on it (a factor tanh = 1: complement q = 0, which the prefix and suffix steps pass
+// through unchanged, sign +), the variable reads 0.0 on it as the last term of its sums (x + 0.0 = x).  The
+// variable-node phase owns both constants: it replaces what the check wrote there by 0.0 when it gathers, and
+// writes +Inf instead of a sum when it scatters; the syndrome toggles skip the edge.  No message ever travels
+// between the two nodes, so nothing the reference keeps apart is joined (a real connection would let a NaN
+// or an infinity of one node reach the other).
+template <int DC, int DV, int RULE, bool EARLY, int VPT, int WPE, bool COUNT = false, bool DEF = false>
 __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
     constexpr int CPT = VPT * DV / DC;
     static_assert(!COUNT || VPT <= 8, "the accounting keeps three 8-bit masks of a thread's variables in one register");
@@ -102,6 +114,12 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
     // kept opaque so that they stay in registers instead of being re-formed as base + offset per use
     const uint32_t lds_base = lds_address(msgb);
     uint32_t off[kLdsVpt][DV];
+    // DEF: lane masks of the short variables among this thread's (their last edge is the extra one)
+    unsigned long long shortm[DEF ? kLdsVpt : 1];
+    auto is_short = [&](int v) -> bool {
+        if constexpr (DEF) return __builtin_amdgcn_inverse_ballot_w64(shortm[v]);
+        return false;
+    };
     {
         // all table reads first, one wait for the lot (made opaque one by one, each read was waited for in turn)
         int raw[kLdsVpt][DV];
@@ -109,6 +127,13 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
         for (int v = 0; v < kLdsVpt; ++v)
 #pragma unroll
             for (int k = 0; k < DV; ++k) raw[v][k] = p.vn_off[(long long)(t + v * nt) * DV + k];
+        if constexpr (DEF) {
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; ++v) {
+                shortm[v] = __ballot((raw[v][DV - 1] & 1) != 0);
+                raw[v][DV - 1] &= ~1;
+            }
+        }
 #pragma unroll
         for (int v = 0; v < kLdsVpt; ++v)
 #pragma unroll
@@ -216,8 +241,15 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
     for (int v = 0; v < kLdsVpt; v += 2)
 #pragma unroll
         for (int k = 0; k < DV; ++k) {
-            lds_store(off[v][k], vl[v / 2].x + 0.0f);
-            lds_store(off[v + 1][k], vl[v / 2].y + 0.0f);
+            float bx = vl[v / 2].x + 0.0f, by = vl[v / 2].y + 0.0f;
+            if constexpr (DEF) {
+                if (k == DV - 1) {
+                    bx = is_short(v) ? __builtin_inff() : bx;
+                    by = is_short(v + 1) ? __builtin_inff() : by;
+                }
+            }
+            lds_store(off[v][k], bx);
+            lds_store(off[v + 1][k], by);
         }
     __syncthreads();
 
@@ -239,6 +271,9 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
                 asm volatile("" : "+v"(o));  // formed here, when needed: 24 more loop invariants do not fit
                 const uint32_t slot = (o - lds_base) >> 2;
                 const uint32_t b = 2u * (slot / (uint32_t)lds_pair_stride(DC)) + (slot & 1u);
+                if constexpr (DEF) {
+                    if (k == DV - 1 && is_short(v)) continue;  // the extra edge is not an edge of the code
+                }
                 atomicXor(&par[b >> 5], 1u << (b & 31u));
             }
         }
@@ -299,11 +334,22 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
         for (int v = 0; v < kLdsVpt; v += 2)
 #pragma unroll
             for (int k = 0; k < DV; ++k) va[v / 2][k] = v2f{lds_load(off[v][k]), lds_load(off[v + 1][k])};
+        if constexpr (DEF) {  // what a short variable's extra edge holds is the check's business: the variable adds 0.0
+#pragma unroll
+            for (int v = 0; v < kLdsVpt; v += 2) {
+                va[v / 2][DV - 1].x = is_short(v) ? 0.0f : va[v / 2][DV - 1].x;
+                va[v / 2][DV - 1].y = is_short(v + 1) ? 0.0f : va[v / 2][DV - 1].y;
+            }
+        }
 #pragma unroll
         for (int v = 0; v < kLdsVpt; v += 2) {
             v2f g;
             vn_compute_v<v2f, DV>(va[v / 2], vl[v / 2], g);   // two variables per packed register
             if (write_beta) {
+                if constexpr (DEF) {  // ... and the check reads a factor of exactly 1 from it
+                    va[v / 2][DV - 1].x = is_short(v) ? __builtin_inff() : va[v / 2][DV - 1].x;
+                    va[v / 2][DV - 1].y = is_short(v + 1) ? __builtin_inff() : va[v / 2][DV - 1].y;
+                }
 #pragma unroll
                 for (int k = 0; k < DV; ++k) {
                     lds_store(off[v][k], va[v / 2][k].x);
@@ -473,14 +519,16 @@ struct LdsLaunch {
     int wpe;  // 4 or 6, see bp_lds_kernel
     int vpt;  // variables per thread: kLdsVpt or kLdsVptWide
     bool count;  // error accounting inside the kernel (default check-node rule, at most 8 variables per thread)
+    bool def = false;  // the code is one edge short of regular in places (bp_lds_kernel, DEF); default rule only
     int threads;
     size_t lds_bytes;
     hipStream_t stream;
 };
 
-template <int DC, int DV, int VPT>
+template <int DC, int DV, int VPT, bool ALLOW_DEF = false>
 inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
     if (l.threads * VPT < p.n || l.threads > 4096 / VPT || l.threads % 64) return hipErrorInvalidConfiguration;
+    if (l.def && (!ALLOW_DEF || l.rule != kCnComplement)) return hipErrorInvalidConfiguration;
     const long long fpw = (l.early && l.frames_per_wg > 0) ? l.frames_per_wg : 1;
     const dim3 grid((unsigned)((p.frames + fpw - 1) / fpw)), block((unsigned)l.threads);
 #define LDPC_LDS2(R, E, W, ...)                                                                              \
@@ -497,6 +545,19 @@ inline hipError_t bp_lds_launch_impl(const LdsLaunch& l, const LdsParams& p) {
         else if constexpr (VPT == kLdsVptMid) LDPC_LDS2(R, E, 4);                                            \
         else if (l.wpe >= 6) LDPC_LDS2(R, E, 6); else LDPC_LDS2(R, E, 4);                                    \
     } while (0)
+    if constexpr (ALLOW_DEF) {
+        if (l.def) {
+            if (l.count) {
+                if (!p.counters) return hipErrorInvalidValue;
+                if (l.early) { if (l.wpe >= 6) LDPC_LDS2(kCnComplement, true, 6, true, true); else LDPC_LDS2(kCnComplement, true, 4, true, true); }
+                else { if (l.wpe >= 6) LDPC_LDS2(kCnComplement, false, 6, true, true); else LDPC_LDS2(kCnComplement, false, 4, true, true); }
+            } else {
+                if (l.early) { if (l.wpe >= 6) LDPC_LDS2(kCnComplement, true, 6, false, true); else LDPC_LDS2(kCnComplement, true, 4, false, true); }
+                else { if (l.wpe >= 6) LDPC_LDS2(kCnComplement, false, 6, false, true); else LDPC_LDS2(kCnComplement, false, 4, false, true); }
+            }
+            return hipGetLastError();
+        }
+    }
     if (l.count) {
         if constexpr (VPT <= kLdsVpt) {
             if (l.rule != kCnComplement || !p.counters) return hipErrorInvalidValue;

@@ -4,7 +4,9 @@
 #include "bp_lds.hpp"
 
 namespace ldpc {
-hipError_t bp_lds_launch_10_5(const LdsLaunch& l, const LdsParams& p) { return bp_lds_launch_impl<10, 5, 4>(l, p); }
+// The same kernels also take the draws with an empty block (one in three): checks of degree 9 - 10, variables of degree
+// 4 - 5, completed with constant extra edges (bp_lds_kernel, DEF).
+hipError_t bp_lds_launch_10_5(const LdsLaunch& l, const LdsParams& p) { return bp_lds_launch_impl<10, 5, 4, true>(l, p); }
 unsigned bp_lds_10_5_params_bytes() { return (unsigned)sizeof(LdsParams); }
 
 }  // namespace ldpc

@@ -45,6 +45,10 @@ struct ldpc_amd_ctx {
     long long E = 0;
     int max_dc = 0, max_dv = 0;
     int reg_dc = 0, reg_dv = 0;  // the common degree when every check / variable has it, else 0
+    // one edge short of regular in places: every check has near_dc or near_dc - 1 edges, every variable near_dv or
+    // near_dv - 1, as many short checks as short variables (a quasi-cyclic code with empty blocks in distinct rows
+    // and columns of its base matrix); else 0
+    int near_dc = 0, near_dv = 0;
     int cn_rule = LDPC_AMD_CN_SUMPRODUCT;
     uint8_t* d_leaf = nullptr;  // leaf_row[m] | leaf_var[n] (BpParams), null when the code has no leaf to mark
     int* d_row_ptr = nullptr;
@@ -184,6 +188,13 @@ void build_graph(ldpc_amd_ctx* c, long long nnz, const int32_t* rows, const int3
     }
     c->reg_dc = (m > 0 && min_dc == c->max_dc) ? c->max_dc : 0;
     c->reg_dv = (n > 0 && min_dv == c->max_dv) ? c->max_dv : 0;
+    c->near_dc = c->near_dv = 0;
+    if (m > 0 && n > 0 && min_dc >= c->max_dc - 1 && min_dv >= c->max_dv - 1 && min_dv >= 1 && (min_dc < c->max_dc || min_dv < c->max_dv) &&
+        (long long)m * c->max_dc == (long long)n * c->max_dv) {
+        // the completed graph has m max_dc = n max_dv edges, so the short checks and the short variables are equally many
+        c->near_dc = c->max_dc;
+        c->near_dv = c->max_dv;
+    }
 }
 
 int ensure_stage(ldpc_amd_ctx* c, int slot, size_t bytes) {
@@ -233,14 +244,41 @@ struct PlaceRng {
 // written.  Every table below is built for that larger graph.
 int build_resident_tables(ldpc_amd_ctx* c, int nt, int vpt) {
     if (c->d_res && c->res_nt == nt && c->res_vpt == vpt) return LDPC_AMD_OK;
-    const int dc = c->reg_dc, dv = c->reg_dv;
+    const bool completed = c->reg_dc == 0 && c->near_dc > 0;  // one edge short of regular in places: see bp_lds_kernel, DEF
+    const int dc = completed ? c->near_dc : c->reg_dc, dv = completed ? c->near_dv : c->reg_dv;
     const int n = vpt * nt, m = (int)((long long)n * dv / dc);
     const long long E = (long long)n * dv;
     const int pad_m = m - c->m;
     if (n < c->n || m < c->m || (long long)m * dc != E || (n > c->n && pad_m < dv))
         return fail(c, LDPC_AMD_EINVAL, "resident tables: the code does not tile");
     std::vector<int> col_edge((size_t)E);  // edge ids (row-major positions in the larger graph) of every variable
-    std::copy(c->h_col_edge.begin(), c->h_col_edge.end(), col_edge.begin());
+    std::vector<char> extra_edge((size_t)n, 0);  // the variable's last edge is the constant one that completes a short node
+    if (!completed) {
+        std::copy(c->h_col_edge.begin(), c->h_col_edge.end(), col_edge.begin());
+    } else {
+        // Edge ids of the completed graph: edge e of check i keeps its place in the row, i dc + (e - row_ptr[i]); a
+        // short check's last place, i dc + dc - 1, goes to a short variable as its last edge (any one-to-one
+        // pairing serves: the edge carries constants).
+        std::vector<int> edge_row((size_t)c->E), short_checks;
+        for (int i = 0; i < c->m; ++i) {
+            for (int e = c->h_row_ptr[(size_t)i]; e < c->h_row_ptr[(size_t)i + 1]; ++e) edge_row[(size_t)e] = i;
+            if (c->h_row_ptr[(size_t)i + 1] - c->h_row_ptr[(size_t)i] == dc - 1) short_checks.push_back(i);
+        }
+        size_t next_short = 0;
+        for (int j = 0; j < c->n; ++j) {
+            const int c0 = c->h_col_ptr[(size_t)j], d = c->h_col_ptr[(size_t)j + 1] - c0;
+            for (int k = 0; k < d; ++k) {
+                const int e = c->h_col_edge[(size_t)c0 + k], i = edge_row[(size_t)e];
+                col_edge[(size_t)j * dv + k] = i * dc + (e - c->h_row_ptr[(size_t)i]);
+            }
+            if (d == dv - 1) {
+                if (next_short >= short_checks.size()) return fail(c, LDPC_AMD_EINVAL, "resident tables: short checks and variables do not pair up");
+                col_edge[(size_t)j * dv + dv - 1] = short_checks[next_short++] * dc + dc - 1;
+                extra_edge[(size_t)j] = 1;
+            }
+        }
+        if (next_short != short_checks.size()) return fail(c, LDPC_AMD_EINVAL, "resident tables: short checks and variables do not pair up");
+    }
     for (int j = c->n; j < n; ++j)
         for (int k = 0; k < dv; ++k) {
             const long long sock = (long long)(j - c->n) * dv + k;
@@ -428,6 +466,7 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt, int vpt) {
         t_perm[p] = perm[(size_t)p];
         t_pos[p] = pos[(size_t)p];
         for (int k = 0; k < dv; ++k) t_vn[(size_t)p * dv + k] = 4 * slot[(size_t)col_edge[(size_t)perm[(size_t)p] * dv + k]];
+        if (extra_edge[(size_t)perm[(size_t)p]]) t_vn[(size_t)p * dv + dv - 1] |= 1;  // offsets are multiples of 4: bit 0 marks the extra edge
     }
     if (c->d_res) {
         LDPC_HIP(c, hipFree(c->d_res));
@@ -596,7 +635,9 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
     const bool early = early_term != 0;
     // Frame-resident engine: regular code whose messages fit at least twice into a CU's LDS.
     if (!noalloc) {
-        const int dcr = c->reg_dc, dvr = c->reg_dv;
+        // a code one edge short of the (10,5) shape in places runs on the same kernels, completed with constant edges
+        const bool def = c->reg_dc == 0 && c->near_dc == 10 && c->near_dv == 5 && c->cn_rule == LDPC_AMD_CN_SUMPRODUCT;
+        const int dcr = def ? c->near_dc : c->reg_dc, dvr = def ? c->near_dv : c->reg_dv;
         const bool shape = (dcr == 6 && dvr == 3) || (dcr == 8 && dvr == 2) || (dcr == 8 && dvr == 4) || (dcr == 10 && dvr == 5);
         // vpt variables and vpt dv / dc checks per thread, whole wavefronts: 8 variables per thread, 4 for the (10,5)
         // kernels; the (6,3) kernels also exist with 12 (chosen below where it tiles better) and 16 (half the threads).  A code whose n is not vpt x 64 x
@@ -644,6 +685,7 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
             if (counting) { q.cw = count->cw; q.counters = count->counters; q.count_rx = count->rx ? 1 : 0; }
             LdsLaunch l;
             l.count = counting;
+            l.def = def;
             l.rule = c->cn_rule == LDPC_AMD_CN_MINSUM ? kCnMinSum
                      : c->cn_rule == LDPC_AMD_CN_SUMPRODUCT_TANH ? kCnSumProduct : kCnComplement;
             l.early = early; l.threads = nt; l.vpt = vpt; l.lds_bytes = lds_bytes; l.stream = s;

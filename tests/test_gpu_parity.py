@@ -612,3 +612,95 @@ def test_sweeps_that_leave_the_leaves_alone_return_the_same_bits(pkg, oracle, en
             frac, diff = _agreement(a, want)
             assert diff.size <= MAX_DIFFERING(F), (name, L, _itemise(a, want, diff))
         dec.close()
+
+
+def _qc_draws_with_empty_blocks(pkg, z, wanted):
+    """Draws of GenerateMatrix.generateQC(z, 5, 10) by the number and placement of their empty blocks."""
+    found = {}
+    for s in range(1, 4000):
+        base, code = pkg.codes.random_qc(z, 5, 10, s)
+        empty = np.asarray(base) < 0
+        k = int(empty.sum())
+        distinct = bool((empty.sum(axis=0) <= 1).all() and (empty.sum(axis=1) <= 1).all())
+        key = (k, distinct)
+        if key in wanted and key not in found:
+            found[key] = code
+        if len(found) == len(wanted):
+            break
+    return found
+
+
+def test_qc_draws_with_empty_blocks_on_the_resident_10_5_kernels(pkg, oracle, engine):
+    """A draw of the reference's random quasi-cyclic construction leaves a block of the 5 x 10 base matrix empty with
+    probability 1/109 per block (GenerateMatrix.java:100): three draws in ten have one empty block (108 checks of
+    degree 9, 108 variables of degree 4), six in a hundred two.  With the empty blocks in distinct rows and columns
+    the code runs on the frame-resident (10,5) kernels, completed with constant extra edges (+Inf towards the
+    check, 0.0 towards the variable); every other draw stays on the generic kernel.  Equal to the double oracle at
+    the 99.99 % bar and bit for bit to the generic resident kernel and the sweeps, with early exit, at fixed
+    iterations, from hard received words with the reference's parity LLRs (which saturate: +-Inf and NaN travel),
+    and in a Monte-Carlo leg with the accounting inside the kernel."""
+    if engine != "resident":
+        pytest.skip("comparison runs once")
+    draws = _qc_draws_with_empty_blocks(pkg, 108, {(1, True), (2, True), (2, False)})
+    small_base = np.array([[(7 * i * j + 3 * i + 5 * j) % 36 for j in range(10)] for i in range(5)])
+    small_base[3, 6] = -1
+    small = {(1, True): pkg.codes.qc_expand(small_base, 36)}       # n = 360, tiled as a larger code
+    # (the hand-made z = 36 base matrix is full of short cycles: at a noise level that leaves frames undecoded most of
+    # them never settle, so it is compared with the oracle where its frames converge)
+    cases = (("z=108, one empty block", draws[(1, True)], "bp_lds_kernel", 2.6),
+             ("z=108, two empty blocks in distinct rows and columns", draws[(2, True)], "bp_lds_kernel", 2.6),
+             ("z=108, two empty blocks in one row or column", draws[(2, False)], "bp_lds_gen_kernel", 2.6),
+             ("z=36, one empty block", small[(1, True)], "bp_lds_kernel", 6.0))
+    F = 1500
+    for name, (m, n, rows, cols), kernel, ebn0 in cases:
+        dec = pkg.Decoder(m, n, rows, cols)
+        g = oracle.Graph(m, n, rows, cols)
+        llr = oracle.gen_awgn_llr(m, n, ebn0, seed=41, first_frame=0, frames=F)
+        for early, L in ((True, 40), (False, 9), (False, 1)):
+            pkg.capi.set_default_options()
+            a = dec.decode_batch(llr, L, early)
+            assert dec.last_decode_kernel() == kernel, name
+            want = g.decode_llr_batch(llr, L, early)
+            _, diff = _agreement(a, want)
+            # every frame the oracle decodes: the same triple.  A frame still oscillating at the last iteration may hold
+            # another word (4-byte messages, see test_hard_decision_agreement_at_scale_irregular): never more than
+            # the oracle's own float model shows on these frames (x 1.5, + 1), and with the same iteration count
+            _, model_diff = _agreement(g.decode_llr_batch(llr, L, early, storage=14), want)
+            assert (want[2][diff] > 0).all() and (a[1][diff] == want[1][diff]).all(), (name, early, _itemise(a, want, diff))
+            assert diff.size <= 1.5 * model_diff.size + 1, (name, early, model_diff.size, _itemise(a, want, diff))
+            if early and ebn0 < 3.0:
+                assert 0 < (a[2] == 0).sum() < F, name               # decoded and undecoded frames
+            for opt, other in (("resident_generic", "bp_lds_gen_kernel"), ("stream_rows", "rows_cn_kernel")):
+                pkg.capi.set_default_options(**ENGINE_OPTIONS[opt])
+                try:
+                    b = dec.decode_batch(llr, L, early)
+                    assert dec.last_decode_kernel() == other
+                finally:
+                    pkg.capi.set_default_options()
+                for x, y in zip(a, b):
+                    assert (x == y).all(), (name, early, other)
+        # the reference's own calling convention: parity positions at +-ln 1e20 saturate every check they fill
+        for Fr, e in ((333, 0.02), (64, 0.05)):
+            r = oracle.gen_bsc(m, n, oracle.CH_BSC_INFO, e, seed=43, first_frame=3, frames=Fr)
+            a = dec.decode_bsc_batch(r, e, 50, oracle.LLR_PARITY_LN1E20, True)
+            assert dec.last_decode_kernel() == kernel
+            want = g.decode_llr_batch_f64(oracle.bsc_llr_batch(m, n, r, e, oracle.LLR_PARITY_LN1E20), 50, True)
+            _, hdiff = _hard_agreement(a, want)
+            assert hdiff.size == 0, (name, Fr, _itemise(a, want, hdiff))
+            pkg.capi.set_default_options(**ENGINE_OPTIONS["stream_rows"])
+            try:
+                b = dec.decode_bsc_batch(r, e, 50, oracle.LLR_PARITY_LN1E20, True)
+            finally:
+                pkg.capi.set_default_options()
+            for x, y in zip(a, b):
+                assert (x == y).all(), (name, Fr)
+        dec.set_option("sim_fused", 1)
+        x = dec.simulate(oracle.CH_AWGN, 2.6, 5, 11, 700, 30, True)
+        dec.set_option("sim_fused", 0)
+        y = dec.simulate(oracle.CH_AWGN, 2.6, 5, 11, 700, 30, True)       # noisy for every case: undecoded frames too
+        assert (x == y).all() and x[0] == 700, (name, x[:12], y[:12])
+        z1 = dec.simulate(oracle.CH_BSC_INFO, 0.03, 5, 11, 500, 30, True)
+        dec.set_option("engine", "stream")
+        z2 = dec.simulate(oracle.CH_BSC_INFO, 0.03, 5, 11, 500, 30, True)
+        assert (z1 == z2).all(), (name, z1[:12], z2[:12])
+        dec.close()

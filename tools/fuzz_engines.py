@@ -26,7 +26,11 @@ def random_code(rng):
         if shape == 4:
             return L.codes.regular_ldpc(20 * int(rng.integers(4, 200)), 5, 10, s)
         z = int(rng.integers(8, 128))
-        return L.codes.qc_expand(rng.integers(0, z, (5, 10)), z)   # a quasi-cyclic (10,5) code without empty blocks
+        base = rng.integers(0, z, (5, 10))
+        if rng.random() < 0.5:   # empty blocks in distinct rows and columns: one edge short of (10,5) in places
+            for r_, c_ in zip(rng.permutation(5)[: int(rng.integers(1, 4))], rng.permutation(10)):
+                base[r_, c_] = -1
+        return L.codes.qc_expand(base, z)   # a quasi-cyclic (10,5) code, with or without empty blocks
     if kind == 0:  # regular (dv, dc)
         dv, dc = [(3, 6), (2, 8), (3, 4), (4, 8), (2, 4)][rng.integers(0, 5)]
         n = int(rng.integers(2, 40)) * dc * (1 if rng.random() < 0.5 else 8)
