@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace ldpc {
 
 constexpr int kWave = 64;
@@ -88,12 +90,67 @@ struct BpParams {
 #ifndef LDPC_MSG_NT
 #define LDPC_MSG_NT 0
 #endif
+// LDPC_LANE_IN_ACCESS (set by a translation unit before this header): the pointers handed to ldv / stv / ldw / stw are
+// the same in every lane of the wavefront - the address of a row - and the lane's own FPL elements are addressed
+// inside the access.  A row address built from wave-uniform values (tile, edge index from a scalar load) then
+// lives in scalar registers and the access is "scalar base + 32-bit lane offset": no pair of vector registers
+// per row in flight (a variable of degree 30 held 60 of them), no 64-bit vector additions.  Without it the
+// caller's pointer already includes the lane.
+#ifndef LDPC_LANE_IN_ACCESS
+#define LDPC_LANE_IN_ACCESS 0
+#endif
+template <int FPL>
+__device__ __forceinline__ unsigned lane_bytes() {  // byte offset of this lane's first element in a row of 4-byte elements
+    return LDPC_LANE_IN_ACCESS ? (unsigned)__lane_id() * (unsigned)(4 * FPL) : 0u;
+}
+template <class T>
+__device__ __forceinline__ T* at_lane(T* p, unsigned bytes) {
+    char* row = reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p));
+    if (LDPC_LANE_IN_ACCESS) {
+        // The row address as a scalar, stated explicitly: left to itself the compiler folds the lane offset into the
+        // tile base once (it does not change from row to row) and then forms every row address with 64-bit vector
+        // additions, one pair of vector registers per row in flight.
+        const unsigned long long a = reinterpret_cast<unsigned long long>(row);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        // (rebuilt as a pointer into global memory, so that the access stays a global one)
+        typedef __attribute__((address_space(1))) char global_char;
+        global_char* g = reinterpret_cast<global_char*>(((unsigned long long)hi << 32) | lo);
+        return reinterpret_cast<T*>((char*)(g + bytes));
+    }
+    return reinterpret_cast<T*>(row + bytes);
+}
+// An edge index the compiler must take from a scalar register as it is, without connecting it to where it came
+// from (LDPC_LANE_IN_ACCESS only: there the index is the same in every lane).  A row address is formed from it
+// on the scalar unit right where it is used, for the load and again for the store; connected, the compiler
+// keeps the 64-bit address of every row of a node in registers from its load to its store (60 registers for a
+// variable of degree 30) instead of the 32-bit index.
+__device__ __forceinline__ int fresh_index(int e) {
+#if LDPC_LANE_IN_ACCESS
+    e = __builtin_amdgcn_readfirstlane(e);
+    asm volatile("" : "+s"(e));
+#endif
+    return e;
+}
+// An entry of one of the graph's index arrays (row and column pointers, edge lists, leaf marks).  With
+// LDPC_LANE_IN_ACCESS the index is the same in every lane and the arrays are never written while a kernel runs:
+// read through the constant address space the load is a scalar one (scalar cache, no vector memory
+// instruction, no round trip through a vector register before the row address can be formed).
+template <class T>
+__device__ __forceinline__ T idx(const T* p, long long i) {
+#if LDPC_LANE_IN_ACCESS
+    typedef const __attribute__((address_space(4))) T constant_T;
+    return ((constant_T*)p)[i];
+#else
+    return p[i];
+#endif
+}
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 template <int FPL>
 __device__ __forceinline__ void ldv(const float* p, float (&v)[FPL]) {
+    p = at_lane(p, lane_bytes<FPL>());
     if constexpr (FPL == 1) {
         v[0] = p[0];
     } else if constexpr (FPL == 2) {
@@ -106,6 +163,7 @@ __device__ __forceinline__ void ldv(const float* p, float (&v)[FPL]) {
 }
 template <int FPL>
 __device__ __forceinline__ void stv(float* p, const float (&v)[FPL]) {
+    p = at_lane(p, lane_bytes<FPL>());
     if constexpr (FPL == 1) {
         p[0] = v[0];
     } else if constexpr (FPL == 2) {
@@ -117,6 +175,7 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[FPL]) {
 }
 template <int FPL>
 __device__ __forceinline__ void ldw(const uint32_t* p, uint32_t (&v)[FPL]) {
+    p = at_lane(p, lane_bytes<FPL>());
     if constexpr (FPL == 1) {
         v[0] = p[0];
     } else if constexpr (FPL == 2) {
@@ -129,6 +188,7 @@ __device__ __forceinline__ void ldw(const uint32_t* p, uint32_t (&v)[FPL]) {
 }
 template <int FPL>
 __device__ __forceinline__ void stw(uint32_t* p, const uint32_t (&v)[FPL]) {
+    p = at_lane(p, lane_bytes<FPL>());
     if constexpr (FPL == 1) {
         p[0] = v[0];
     } else if constexpr (FPL == 2) {
@@ -368,7 +428,7 @@ __device__ __forceinline__ void cn_row(float* row, const float* lam, const int* 
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         if constexpr (FIRST) {
-            ldv<FPL>(lam + (long long)cols[k] * LT, b[k]);
+            ldv<FPL>(lam + (long long)idx(cols, k) * LT, b[k]);
 #pragma unroll
             for (int f = 0; f < FPL; ++f) b[k][f] += 0.0f;
         } else {
@@ -381,6 +441,10 @@ __device__ __forceinline__ void cn_row(float* row, const float* lam, const int* 
         if (k + 1 < D || !skip_last) stv<FPL>(row + (long long)k * T, b[k]);  // skip_last: see BpParams::leaf_row
 }
 
+// one element of this lane (one frame per lane): the staged paths below
+__device__ __forceinline__ float ld1(const float* p) { float v[1]; ldv<1>(p, v); return v[0]; }
+__device__ __forceinline__ void st1(float* p, float x) { const float v[1] = {x}; stv<1>(p, v); }
+
 // Any degree up to the LDS capacity, one frame per lane: tanh values and exclusive prefix
 // products of the row are staged in LDS as [k][lane] (conflict-free), then combined with
 // the running suffix product on the way back.
@@ -392,7 +456,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
     if constexpr (RULE == kCnSumProduct) {
         float pre = 1.0f;
         for (int k = 0; k < d; ++k) {
-            float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
+            float b = FIRST ? (ld1(lam + (long long)idx(cols, k) * LT) + 0.0f) : ld1(row + (long long)k * T);
             const float t = tanh_half(b);
             st[k * 64] = t;
             sp[k * 64] = pre;
@@ -402,7 +466,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
         for (int k = d - 1; k >= 0; --k) {
             const float p = sp[k * 64] * suf;
             suf *= st[k * 64];
-            row[(long long)k * T] = atanh2(p);
+            st1(row + (long long)k * T, atanh2(p));
         }
     } else if constexpr (RULE == kCnComplement) {
 #pragma clang fp contract(off)
@@ -410,7 +474,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
         float Q = 0.0f;
         uint32_t psg = 0u;
         for (int k = 0; k < d; ++k) {
-            const float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
+            const float b = FIRST ? (ld1(lam + (long long)idx(cols, k) * LT) + 0.0f) : ld1(row + (long long)k * T);
             const uint32_t sg = __float_as_uint(b) & 0x80000000u;
             const float qk = tanh_complement<float>(b);
             st[k * 64] = __uint_as_float(__float_as_uint(qk) | sg);
@@ -424,7 +488,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
             const float sv = st[k * 64], pv = sp[k * 64];
             const float qk = fabsf(sv), pq = fabsf(pv);
             const float mag = atanh2_complement<float>(fmaf(sQ, 1.0f - pq, pq));
-            row[(long long)k * T] = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(pv) & 0x80000000u) ^ ssg);
+            st1(row + (long long)k * T, __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(pv) & 0x80000000u) ^ ssg));
             sQ = fmaf(qk, 1.0f - sQ, sQ);
             ssg ^= __float_as_uint(sv) & 0x80000000u;
         }
@@ -433,7 +497,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
         // of row k is rebuilt from the staged beta on the way back (this path is rare).
         float pm = 3.402823466e+38f;
         for (int k = 0; k < d; ++k) {
-            float b = FIRST ? (lam[(long long)cols[k] * LT] + 0.0f) : row[(long long)k * T];
+            float b = FIRST ? (ld1(lam + (long long)idx(cols, k) * LT) + 0.0f) : ld1(row + (long long)k * T);
             st[k * 64] = b;
             sp[k * 64] = pm;
             const float a = fabsf(b);
@@ -446,7 +510,7 @@ __device__ __forceinline__ void cn_row_lds(float* row, const float* lam, const i
             for (int q = 0; q < k; ++q) psign *= signum(st[q * 64]);
             const float pmin = sp[k * 64];
             const float mn = (pmin > sm) ? sm : pmin;
-            row[(long long)k * T] = psign * ss * mn * 0.7f;
+            st1(row + (long long)k * T, psign * ss * mn * 0.7f);
             ss *= signum(b);
             const float a = fabsf(b);
             sm = (sm > a) ? a : sm;
@@ -512,15 +576,15 @@ __device__ __forceinline__ void vn_col(float* msg, const float* lamrow, const in
         for (int f = 0; f < FPL; ++f) g[f] = lam[f];
     } else {
         float a[D][FPL];
-        long long off[D];
+        int ek[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) off[k] = (long long)edges[k] * T;
+        for (int k = 0; k < D; ++k) ek[k] = idx(edges, k);
 #pragma unroll
-        for (int k = 0; k < D; ++k) ldv<FPL>(msg + off[k], a[k]);
+        for (int k = 0; k < D; ++k) ldv<FPL>(msg + (long long)ek[k] * T, a[k]);
         vn_compute<FPL, D>(a, lam, g);
         if (write_beta) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) stv<FPL>(msg + off[k], a[k]);
+            for (int k = 0; k < D; ++k) stv<FPL>(msg + (long long)fresh_index(ek[k]) * T, a[k]);
         }
     }
 }
@@ -529,9 +593,9 @@ __device__ __forceinline__ float vn_col_lds(float* msg, const float* lamrow, con
                                             bool write_beta, float* lds, int cap, int lane) {
     float* sa = lds + lane;                        // alpha
     float* sp = lds + (long long)cap * 64 + lane;  // prefix sums
-    float pre = lamrow[0];
+    float pre = ld1(lamrow);
     for (int k = 0; k < d; ++k) {
-        const float a = msg[(long long)edges[k] * T];
+        const float a = ld1(msg + (long long)idx(edges, k) * T);
         sa[k * 64] = a;
         sp[k * 64] = pre;
         pre += a;
@@ -540,7 +604,7 @@ __device__ __forceinline__ float vn_col_lds(float* msg, const float* lamrow, con
         float suf = 0.0f;
         for (int k = d - 1; k >= 0; --k) {
             const float a = sa[k * 64];
-            msg[(long long)edges[k] * T] = (k == d - 1) ? sp[k * 64] : (sp[k * 64] + suf);
+            st1(msg + (long long)idx(edges, k) * T, (k == d - 1) ? sp[k * 64] : (sp[k * 64] + suf));
             suf = (k == d - 1) ? a : (a + suf);
         }
     }
@@ -620,7 +684,7 @@ __device__ __forceinline__ void cn_load_at(const BpParams& p, const float* msg, 
                                            float (&b)[D][FPL]) {
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        if constexpr (FIRST) ldv<FPL>(lam + (long long)p.edge_col[e0 + k] * p.lam_row, b[k]);
+        if constexpr (FIRST) ldv<FPL>(lam + (long long)idx(p.edge_col, e0 + k) * p.lam_row, b[k]);
         else                 ldv<FPL>(msg + (e0 + k) * p.msg_row, b[k]);
     }
 }
@@ -676,7 +740,7 @@ __device__ __forceinline__ int cn_run(const BpParams& p, float* msg, const float
         bool run = i + G <= i1;
         if (run) {
 #pragma unroll
-            for (int g = 2; g <= G; ++g) run = run && (p.row_ptr[i + g] - e0 == g * D);
+            for (int g = 2; g <= G; ++g) run = run && (idx(p.row_ptr, i + g) - e0 == g * D);
         }
         if (run) {
             float buf[G][D][FPL];
@@ -684,14 +748,14 @@ __device__ __forceinline__ int cn_run(const BpParams& p, float* msg, const float
             for (int g = 0; g < G; ++g) cn_load_at<FPL, D, FIRST>(p, msg, lam, (long long)e0 + g * D, buf[g]);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                cn_finish_at<FPL, D, RULE, FIRST>(p, msg, (long long)e0 + g * D, buf[g], p.leaf_skip && p.leaf_row[i + g]);
+                cn_finish_at<FPL, D, RULE, FIRST>(p, msg, (long long)e0 + g * D, buf[g], p.leaf_skip && idx(p.leaf_row, i + g));
                 __builtin_amdgcn_sched_barrier(0);  // one row's temporaries at a time
             }
             return G;
         }
     }
     cn_row<FPL, D, RULE, FIRST>(msg + (long long)e0 * p.msg_row, lam, p.edge_col + e0, p.msg_row, p.lam_row,
-                                p.leaf_skip && p.leaf_row[i]);
+                                p.leaf_skip && idx(p.leaf_row, i));
     return 1;
 }
 
@@ -708,8 +772,8 @@ __device__ __forceinline__ void cn_rows_any(const BpParams& p, float* msg, const
                                             int lane) {
     int i = i0;
     while (i < i1) {
-        const int e0 = p.row_ptr[i];
-        const int d = p.row_ptr[i + 1] - e0;
+        const int e0 = idx(p.row_ptr, i);
+        const int d = idx(p.row_ptr, i + 1) - e0;
         switch (d) {
             LDPC_RUN_CN(1) LDPC_RUN_CN(2) LDPC_RUN_CN(3) LDPC_RUN_CN(4) LDPC_RUN_CN(5) LDPC_RUN_CN(6)
             LDPC_RUN_CN(7) LDPC_RUN_CN(8) LDPC_RUN_CN(9) LDPC_RUN_CN(10) LDPC_RUN_CN(11) LDPC_RUN_CN(12)
@@ -718,7 +782,7 @@ __device__ __forceinline__ void cn_rows_any(const BpParams& p, float* msg, const
             default: break;
         }
         cn_dispatch<FPL, RULE, FIRST>(d, msg + (long long)e0 * p.msg_row, lam, p.edge_col + e0, p.msg_row, p.lam_row, lds,
-                                      p.lds_maxd, lane, p.leaf_skip && p.leaf_row[i]);
+                                      p.lds_maxd, lane, p.leaf_skip && idx(p.leaf_row, i));
         ++i;
     }
 }
@@ -757,7 +821,7 @@ __device__ __forceinline__ void flush_decisions(const BpParams& p, uint32_t* bit
     uint32_t* word = bits + (long long)(j >> 5) * p.bits_row;
     if (p.bits_bytes) {
 #pragma unroll
-        for (int f = 0; f < FPL; ++f) reinterpret_cast<uint8_t*>(word + f)[(j >> 3) & 3] = (uint8_t)(acc[f] >> (j & 24));
+        for (int f = 0; f < FPL; ++f) reinterpret_cast<uint8_t*>(at_lane(word, lane_bytes<FPL>()) + f)[(j >> 3) & 3] = (uint8_t)(acc[f] >> (j & 24));
     } else {
         stw<FPL>(word, acc);
     }
@@ -770,16 +834,16 @@ template <int FPL, int D>
 struct VnBuf {
     float a[D][FPL];
     float lam[FPL];
-    long long off[D];
+    int e[D];  // CSR edge ids of the variable's messages
 };
 
 template <int FPL, int D>
 __device__ __forceinline__ void vn_load_at(const BpParams& p, const float* msg, const float* lam, int j, long long c0,
                                            VnBuf<FPL, D>& b) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) b.off[k] = (long long)p.col_edge[c0 + k] * p.msg_row;
+    for (int k = 0; k < D; ++k) b.e[k] = idx(p.col_edge, c0 + k);
 #pragma unroll
-    for (int k = 0; k < D; ++k) ldv<FPL>(msg + b.off[k], b.a[k]);
+    for (int k = 0; k < D; ++k) ldv<FPL>(msg + (long long)b.e[k] * p.msg_row, b.a[k]);
     ldv<FPL>(lam + (long long)j * p.lam_row, b.lam);
 }
 
@@ -795,7 +859,7 @@ __device__ __forceinline__ void vn_finish(const BpParams& p, float* msg, uint32_
     vn_compute<FPL, D>(b.a, b.lam, g);
     if (write_beta) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) stv<FPL>(msg + b.off[k], b.a[k]);
+        for (int k = 0; k < D; ++k) stv<FPL>(msg + (long long)fresh_index(b.e[k]) * p.msg_row, b.a[k]);
     }
 #pragma unroll
     for (int f = 0; f < FPL; ++f) acc[f] |= (g[f] < 0.0f ? 1u : 0u) << (j & 31);  // "(gamma[j] < 0) ? 1 : 0", :104
@@ -830,7 +894,7 @@ __device__ __forceinline__ int vn_run(const BpParams& p, float* msg, const float
     bool run = G > 1 && j + G <= j1;
     if (run) {
 #pragma unroll
-        for (int g = 2; g <= G; ++g) run = run && (p.col_ptr[j + g] - c0 == g * D);
+        for (int g = 2; g <= G; ++g) run = run && (idx(p.col_ptr, j + g) - c0 == g * D);
     }
     if (run) {
         VnBuf<FPL, D> buf[G];
@@ -865,9 +929,9 @@ __device__ __forceinline__ void vn_cols_any(const BpParams& p, float* msg, const
     for (int f = 0; f < FPL; ++f) acc[f] = 0u;
     int j = j0;
     while (j < j1) {
-        const int c0 = p.col_ptr[j];
-        const int d = p.col_ptr[j + 1] - c0;
-        if (p.leaf_skip && p.leaf_var[j]) {  // its slot keeps lambda and nobody reads its decision (BpParams::leaf_row)
+        const int c0 = idx(p.col_ptr, j);
+        const int d = idx(p.col_ptr, j + 1) - c0;
+        if (p.leaf_skip && idx(p.leaf_var, j)) {  // its slot keeps lambda and nobody reads its decision (BpParams::leaf_row)
             flush_decisions<FPL>(p, bits, j, acc);
             ++j;
             continue;

@@ -1,6 +1,7 @@
 // Row-parallel sweep launches (see bp_rows.hpp).
 #define LDPC_ROWS_KERNELS
 #define LDPC_MSG_NT 1
+#define LDPC_LANE_IN_ACCESS 1
 // these kernels keep checks up to degree 20 and variables up to degree 32 in registers
 #define LDPC_REG_DEG_CN 20
 #define LDPC_REG_DEG_VN 32

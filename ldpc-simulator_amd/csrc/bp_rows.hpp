@@ -39,6 +39,7 @@ struct RowsParams {
 };
 
 #ifdef LDPC_ROWS_KERNELS  // the kernels are compiled in bp_rows.hip only
+static_assert(LDPC_LANE_IN_ACCESS == 1, "these kernels hand wave-uniform row addresses to the accesses");
 
 template <int FPL>
 __device__ __forceinline__ bool rows_lane_active(const RowsParams& p, int tile, int lane) {
@@ -55,7 +56,7 @@ __device__ __forceinline__ void rows_syndrome(const BpParams& b, const uint32_t*
 #pragma unroll
     for (int f = 0; f < FPL; ++f) w[f] = 0;
     for (int i = i0; i < i1; ++i) {
-        const int e0 = b.row_ptr[i], e1 = b.row_ptr[i + 1];
+        const int e0 = idx(b.row_ptr, i), e1 = idx(b.row_ptr, i + 1);
         uint32_t par[FPL];
 #pragma unroll
         for (int f = 0; f < FPL; ++f) par[f] = 0u;
@@ -64,7 +65,7 @@ __device__ __forceinline__ void rows_syndrome(const BpParams& b, const uint32_t*
             int j[8];
             uint32_t v[8][FPL];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) j[u] = b.edge_col[e + u];
+            for (int u = 0; u < 8; ++u) j[u] = idx(b.edge_col, e + u);
 #pragma unroll
             for (int u = 0; u < 8; ++u) ldw<FPL>(bits + (long long)(j[u] >> 5) * b.bits_row, v[u]);
 #pragma unroll
@@ -76,7 +77,7 @@ __device__ __forceinline__ void rows_syndrome(const BpParams& b, const uint32_t*
             int j[8];
             uint32_t v[8][FPL];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) j[u] = (e + u < e1) ? b.edge_col[e + u] : -1;
+            for (int u = 0; u < 8; ++u) j[u] = (e + u < e1) ? idx(b.edge_col, e + u) : -1;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (j[u] >= 0) ldw<FPL>(bits + (long long)(j[u] >> 5) * b.bits_row, v[u]);
@@ -103,17 +104,20 @@ __global__ void __launch_bounds__(256, 4) rows_cn_kernel(RowsParams p) {
     extern __shared__ float lds_all[];
     float* lds = lds_all + (long long)(threadIdx.x >> 6) * 2 * p.b.lds_maxd * 64;
     const int lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // the same in every lane of a wavefront: as a scalar, everything indexed by it (row and column pointers, edge lists,
+    // row addresses) is scalar loads and scalar arithmetic, and a row address costs no vector registers
+    const int chunk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int tile = blockIdx.y;
     const int i0 = chunk * p.rows_per_chunk;
     if (i0 >= p.b.m) return;
     const int i1 = min(p.b.m, i0 + p.rows_per_chunk);
-    float* msg = p.b.ws_msg + (long long)tile * p.b.msg_tile + lane * FPL;
-    const float* lam = p.b.ws_lam + (long long)tile * p.b.lam_tile + lane * FPL;
+    // row addresses, the same in every lane: the accesses add the lane (LDPC_LANE_IN_ACCESS)
+    float* msg = p.b.ws_msg + (long long)tile * p.b.msg_tile;
+    const float* lam = p.b.ws_lam + (long long)tile * p.b.lam_tile;
     if (rows_lane_active<FPL>(p, tile, lane)) {
         if constexpr (FUSED) {  // weight of the previous iteration's syndrome over this wave's rows
             int w[1];
-            rows_syndrome<1>(p.b, p.b.ws_bits + (long long)tile * p.b.bits_tile + lane, i0, i1, w);
+            rows_syndrome<1>(p.b, p.b.ws_bits + (long long)tile * p.b.bits_tile, i0, i1, w);
             if (w[0]) atomicAdd(&p.st_acc[(long long)((p.iter - 1) & 1) * p.slots + (long long)tile * kWave + lane], w[0]);
         }
         if constexpr (DC > 0) {
@@ -139,14 +143,16 @@ __global__ void __launch_bounds__(256, 4) rows_vn_kernel(RowsParams p, int write
     extern __shared__ float lds_all[];
     float* lds = lds_all + (long long)(threadIdx.x >> 6) * 2 * p.b.lds_maxd * 64;
     const int lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // the same in every lane of a wavefront: as a scalar, everything indexed by it (row and column pointers, edge lists,
+    // row addresses) is scalar loads and scalar arithmetic, and a row address costs no vector registers
+    const int chunk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int tile = blockIdx.y;
     const int j0 = chunk * p.vars_per_chunk;
     if (j0 >= p.b.n) return;
     const int j1 = min(p.b.n, j0 + p.vars_per_chunk);
-    float* msg = p.b.ws_msg + (long long)tile * p.b.msg_tile + lane * FPL;
-    const float* lam = p.b.ws_lam + (long long)tile * p.b.lam_tile + lane * FPL;
-    uint32_t* bits = p.b.ws_bits + (long long)tile * p.b.bits_tile + lane * FPL;
+    float* msg = p.b.ws_msg + (long long)tile * p.b.msg_tile;
+    const float* lam = p.b.ws_lam + (long long)tile * p.b.lam_tile;
+    uint32_t* bits = p.b.ws_bits + (long long)tile * p.b.bits_tile;
     bool active = rows_lane_active<FPL>(p, tile, lane);
     if constexpr (FUSED) {
         {
@@ -189,18 +195,20 @@ __global__ void __launch_bounds__(256, 4) rows_vn_kernel(RowsParams p, int write
 template <int FPL>
 __global__ void __launch_bounds__(256, 4) rows_synd_kernel(RowsParams p) {
     const int lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // the same in every lane of a wavefront: as a scalar, everything indexed by it (row and column pointers, edge lists,
+    // row addresses) is scalar loads and scalar arithmetic, and a row address costs no vector registers
+    const int chunk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int tile = blockIdx.y;
     const int i0 = chunk * p.rows_per_chunk;
     if (i0 >= p.b.m) return;
     const int i1 = min(p.b.m, i0 + p.rows_per_chunk);
-    const uint32_t* bits = p.b.ws_bits + (long long)tile * p.b.bits_tile + lane * FPL;
+    const uint32_t* bits = p.b.ws_bits + (long long)tile * p.b.bits_tile;
     if (!rows_lane_active<FPL>(p, tile, lane)) return;
     int w[FPL];
 #pragma unroll
     for (int f = 0; f < FPL; ++f) w[f] = 0;
     for (int i = i0; i < i1; ++i) {
-        const int e0 = p.b.row_ptr[i], e1 = p.b.row_ptr[i + 1];
+        const int e0 = idx(p.b.row_ptr, i), e1 = idx(p.b.row_ptr, i + 1);
         uint32_t par[FPL];
 #pragma unroll
         for (int f = 0; f < FPL; ++f) par[f] = 0u;
@@ -210,7 +218,7 @@ __global__ void __launch_bounds__(256, 4) rows_synd_kernel(RowsParams p) {
             uint32_t v[4][FPL];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                j[u] = p.b.edge_col[e + u];
+                j[u] = idx(p.b.edge_col, e + u);
                 ldw<FPL>(bits + (long long)(j[u] >> 5) * p.b.bits_row, v[u]);
             }
 #pragma unroll
@@ -219,7 +227,7 @@ __global__ void __launch_bounds__(256, 4) rows_synd_kernel(RowsParams p) {
                 for (int f = 0; f < FPL; ++f) par[f] ^= v[u][f] >> (j[u] & 31);
         }
         for (; e < e1; ++e) {
-            const int j = p.b.edge_col[e];
+            const int j = idx(p.b.edge_col, e);
             uint32_t v[FPL];
             ldw<FPL>(bits + (long long)(j >> 5) * p.b.bits_row, v);
 #pragma unroll
