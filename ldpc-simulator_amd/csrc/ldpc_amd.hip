@@ -978,10 +978,11 @@ int decode_dev(ldpc_amd_ctx* c, const SrcArgs& src, long long frames, int max_it
         if (c->opt.rows_waves && (long long)chunks * tiles_per_round > want)
             chunks = (int)std::max<long long>(1, (want + tiles_per_round - 1) / tiles_per_round);
         // Early termination: the syndrome rides in the check-node launch of the next iteration (two launches per
-        // iteration instead of four, but a converged frame is recognised one check-node sweep later) where that
-        // measured faster on one box: the specialised kernels at every batch size (-8 %), other codes while
-        // the launch is small (NR-BG1-sized code: -14 % at 64 frames, +2 % at 1024, +4.5 % at 65,536).
-        fuse_syndrome = early && fpl == 1 && (specialised || (long long)chunks * tiles_per_round < want);
+        // iteration instead of four; a converged frame is recognised one check-node sweep later).  Faster than
+        // launches of its own at every batch size measured, for every kind of code (NR-BG1-sized code -6 to -8 %
+        // from 256 to 65,536 frames, DVB-S2-shaped code -11 %, (3,6) codes -8 %); before the sweeps formed their row
+        // addresses on the scalar unit it had cost the large batches of irregular codes 4.5 %.
+        fuse_syndrome = early && fpl == 1;
         if (c->opt.rows_fused >= 0) fuse_syndrome = early && fpl == 1 && c->opt.rows_fused != 0;
         if (fpl == 1 && !specialised && (long long)chunks * tiles_per_round < want) {
             const long long finest = std::max(1, std::min(c->m / 2, n / 8));
