@@ -155,6 +155,22 @@ def test_c2_awgn_early_exit(c2, oracle):
     assert (_syndrome_weight(H, got[0]) == got[2]).all()
 
 
+
+
+def _cancelling_posteriors(g, lam, L):
+    """(decisions, mask) of the double oracle after exactly L iterations: mask marks the variables whose posterior
+    gamma = lambda + sum(alpha) (LogDecoder.java:98-103) is a sum of finite terms that cancels to nothing,
+    |gamma| <= 1e-9 * (|lambda| + sum |alpha|).  The sign of such a sum (LogDecoder.java:104) is decided by the
+    rounding of its terms alone."""
+    _, col = g.csr()
+    lam = np.asarray(lam, np.float64)
+    hard, _, _, alpha, _ = g.decode_llr(lam, L, False, messages=True)
+    with np.errstate(invalid="ignore"):
+        gamma = lam + np.bincount(col, weights=alpha, minlength=g.n)
+        size = np.abs(lam) + np.bincount(col, weights=np.abs(alpha), minlength=g.n)
+        return hard, np.isfinite(gamma) & np.isfinite(size) & (np.abs(gamma) <= 1e-9 * size)
+
+
 def test_c2_literal_tanh_rule_documented_divergence(c2, oracle, pkg):
     """The literal fp32 tanh-product rule saturates at |beta| ~ 17 (double: ~ 38) and rounds
     1 - tanh coarsely above |beta| ~ 10; it still decodes, but converges an iteration early or
@@ -169,7 +185,10 @@ def test_c2_literal_tanh_rule_documented_divergence(c2, oracle, pkg):
     frac, diff = _agreement(got, want)
     hfrac, hdiff = _hard_agreement(got, want)
     print("literal tanh rule: hard decisions differ on %d, triples on %d of %d frames" % (hdiff.size, diff.size, F))
-    assert hfrac >= 0.995 and frac >= 0.98
+    # measured: 0 words and 5 of 3,000 triples differ, by one or two iterations
+    assert hdiff.size == 0, _itemise(got, want, hdiff)
+    assert diff.size <= F // 200 and (np.abs(got[1][diff].astype(int) - want[1][diff].astype(int)) <= 2).all(), \
+        _itemise(got, want, diff)
 
 
 def test_c2_fixed_iterations_four_frames_per_lane(c2, oracle):
@@ -553,20 +572,35 @@ def test_resident_kernels_of_the_other_regular_shapes_and_tiled_lengths(pkg, ora
                     assert (x == y).all(), (name, early, kernel)
         # the reference's own calling convention, and ragged batch sizes
         e = 0.02 if n > 600 else 0.01
-        for Fr in (1, 63, 130):
+        for Fr in (1, 63, 130, 1000):
             r = oracle.gen_bsc(m, n, oracle.CH_BSC_INFO, e, seed=33, first_frame=7, frames=Fr)
             a = dec.decode_bsc_batch(r, e, 50, oracle.LLR_PARITY_LN1E20, True)
             assert dec.last_decode_kernel() == "bp_lds_kernel"
-            want = g.decode_llr_batch_f64(oracle.bsc_llr_batch(m, n, r, e, oracle.LLR_PARITY_LN1E20), 50, True)
-            # The words must be equal (the 99.99 % bar).  On the (3,6) codes a hard received word leaves posteriors
-            # that are exactly zero in exact arithmetic after the first iteration (a flipped bit with checks whose
+            lam = oracle.bsc_llr_batch(m, n, r, e, oracle.LLR_PARITY_LN1E20)
+            want = g.decode_llr_batch_f64(lam, 50, True)
+            # The words must be equal (the 99.99 % bar), and the whole triple too, except on a frame in which the
+            # double decode itself meets a posterior that cancels to nothing before it stops.  On the (3,6) codes a
+            # hard received word leaves such posteriors after the first iteration (a flipped bit with checks whose
             # other members are one information bit and four error-free parity bits, and two checks of equal and
-            # opposite messages: -l0 + a + l0 - a); rounding decides their sign, so fp32 and double may stop an
-            # iteration apart with the same word - every engine alike.  Up to 5 % of such frames are let through.
+            # opposite messages: -l0 + a + l0 - a, zero in exact arithmetic); rounding alone decides their sign, so
+            # fp32 and double may stop an iteration apart with the same word - every engine alike.
             _, hdiff = _hard_agreement(a, want)
             assert hdiff.size == 0, (name, Fr, _itemise(a, want, hdiff))
             frac, diff = _agreement(a, want)
-            assert diff.size <= (max(1, Fr // 20) if name.startswith("(3,6)") else 0), (name, Fr, _itemise(a, want, diff))
+            # At the iteration where the first of the two stops, the decisions of the GPU and of the double decoder
+            # may differ only in variables whose posterior cancels in the double decoder.
+            assert name.startswith("(3,6)") or diff.size == 0, (name, Fr, _itemise(a, want, diff))
+            for f in diff:
+                L = int(min(a[1][f], want[1][f]))
+                assert a[2][f] == want[2][f] == 0 and abs(int(a[1][f]) - int(want[1][f])) == 1, (name, Fr, int(f))
+                at_l = dec.decode_bsc_batch(r[f:f + 1], e, L, oracle.LLR_PARITY_LN1E20, False)[0][0]
+                o_at_l, cancels = _cancelling_posteriors(g, lam[f], L)
+                where = np.nonzero(at_l != o_at_l)[0]
+                assert where.size > 0 and cancels[where].all(), (name, Fr, int(f), where[:10], cancels.sum())
+            if Fr == 1000:
+                print("%s, BSC e = %g, %d frames: %d stop an iteration apart on the GPU and in the double oracle, each "
+                      "through decisions on cancelling posteriors only; 0 with another word" % (name, e, Fr, diff.size))
+                assert diff.size <= Fr // 20
         # a leg with the accounting inside the kernel against the counting pass
         dec.set_option("sim_fused", 1)
         x = dec.simulate(oracle.CH_AWGN, ebn0, 5, 11, 700, 30, True)
