@@ -30,7 +30,7 @@ struct LdsParams {
                            // tiling, which is larger than the code when n is not (variables per thread) x blockDim.x
     long long E;
     int msg_words;         // floats of LDS the messages take: (m / 2) * lds_pair_stride(DC)
-    // Tables built once per code on the host (ldpc_amd.hip, build_resident_tables):
+    // Tables built once per code on the host (host_tables.hip, build_resident_tables):
     const int* perm;       // [n]  variable handled at VN position p (thread p % nt, step p / nt)
     const int* pos_of_var; // [n]  inverse of perm
     const int* vn_off;     // [n*DV] byte offset in msg of edge k of the variable at position p, [p*DV + k]
