@@ -145,7 +145,7 @@ int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
 #define LDPC_AMD_OPT_TUNE_GENERIC_THREADS 110 /* generic frame-resident kernel: threads per frame (multiple of 64, 64..512), 0 = by code size */
 #define LDPC_AMD_OPT_TUNE_LDS_VPT 111         /* frame-resident (6,3) kernels: variables per thread (8, 12 or 16; 0 = by code length) */
 #define LDPC_AMD_OPT_TUNE_ROWS_FUSED 109     /* sweeps with early termination: syndrome inside the check-node launch
-                                               of the next iteration (1), in launches of its own (0), -1 = by batch size */
+                                               of the next iteration (1), in launches of its own (0), -1 = the library's choice (inside, at every batch size) */
 #define LDPC_AMD_OPT_TUNE_ROWS_LEAVES 112    /* sweeps at fixed iterations: 1 (default) = iterations 1 .. L-2 leave variables of
                                                 degree 1 alone (same results, less traffic); 0 = every sweep touches them */
 #define LDPC_AMD_OPT_TUNE_SIM_CHUNK_MB 113   /* ldpc_amd_simulate: MiB of received and decoded words per chunk of a leg (default 2048;
