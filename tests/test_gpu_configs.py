@@ -26,14 +26,31 @@ def test_config4_bg1_sized_code_from_file(tmp_path, pkg, oracle):
     dec = pkg.Decoder(m2, n2, r2, c2)
     assert dec.E == 121344 and dec.max_dc == 19 and dec.max_dv == 30
     g = oracle.Graph(m, n, rows, cols)
-    F = 96
+    F = 512
     llr = oracle.gen_awgn_llr(m, n, 2.0, seed=4, first_frame=0, frames=F)
     for early, L in ((True, 25), (False, 8)):
         got = dec.decode_batch(llr, L, early)
         want = g.decode_llr_batch(llr, L, early)
         assert (got[0] == want[0]).all(), "hard decisions differ from the oracle"
         assert (got[1] == want[1]).all() and (got[2] == want[2]).all()
-        assert (_syndrome_weight_sparse(m, rows, cols, got[0]) == got[2]).all()
+        assert (_syndrome_weight_sparse(m, rows, cols, got[0][:96]) == got[2][:96]).all()
+    # the waterfall of this code, where frames run out of iterations: every frame the oracle decodes must be
+    # equal, the others may differ where the oracle's own float model of the kernels does (4-byte messages decide
+    # the last word of a frame that never settles differently from 8-byte ones; measured: none on this code)
+    for ebn0, F in ((0.3, 128), (0.1, 128)):
+        llr = oracle.gen_awgn_llr(m, n, ebn0, seed=4, first_frame=0, frames=F)
+        got = dec.decode_batch(llr, 50, True)
+        want = g.decode_llr_batch(llr, 50, True)
+        model = g.decode_llr_batch(llr, 50, True, storage=14)
+        differ = np.array([not ((a[0][f] == want[0][f]).all() and a[1][f] == want[1][f] and a[2][f] == want[2][f])
+                           for a in (got, model) for f in range(F)]).reshape(2, F)
+        undecoded = want[2] > 0
+        print("BG1-sized Z = 384 at %.1f dB: %d of %d frames undecoded in the oracle; triples that differ from it: GPU %d, "
+              "its float model %d" % (ebn0, int(undecoded.sum()), F, int(differ[0].sum()), int(differ[1].sum())))
+        assert 0 < undecoded.sum() < F
+        assert not (differ[0] & ~undecoded).any(), "a frame the oracle decodes differs"
+        assert differ[0].sum() <= 1.5 * differ[1].sum() + 3
+        assert (_syndrome_weight_sparse(m, rows, cols, got[0][:32]) == got[2][:32]).all()
     # a batch the oracle could not keep up with: properties only
     import torch
     F = 4096
