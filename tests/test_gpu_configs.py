@@ -73,13 +73,31 @@ def test_config5_long_code_small_batch_early_exit(pkg, oracle):
     m, n, rows, cols = pkg.codes.regular_ldpc(64800, 3, 6, seed=1)
     dec = pkg.Decoder(m, n, rows, cols)
     g = oracle.Graph(m, n, rows, cols)
-    for F in (1, 8):
+    for F, kernel in ((1, "bp_nodes_kernel"), (8, None), (200, "rows_cn_kernel")):
         llr = oracle.gen_awgn_llr(m, n, 1.6, seed=6, first_frame=0, frames=F)
         got = dec.decode_batch(llr, 50, True)
+        if kernel:
+            assert dec.last_decode_kernel() == kernel
         want = g.decode_llr_batch(llr, 50, True)
         assert (got[0] == want[0]).all()
         assert (got[1] == want[1]).all() and (got[2] == want[2]).all()
         assert (got[1] < 50).all() and (got[2] == 0).all()
+    # the waterfall of this code (1.2 and 1.15 dB: frames that run out of iterations), one batch of a size for
+    # each of the two engines that take it; measured: every triple equal, the undecoded frames included
+    for ebn0, F in ((1.2, 64), (1.15, 6)):
+        llr = oracle.gen_awgn_llr(m, n, ebn0, seed=6, first_frame=0, frames=F)
+        got = dec.decode_batch(llr, 50, True)
+        want = g.decode_llr_batch(llr, 50, True)
+        model = g.decode_llr_batch(llr, 50, True, storage=14)
+        differ = np.array([not ((a[0][f] == want[0][f]).all() and a[1][f] == want[1][f] and a[2][f] == want[2][f])
+                           for a in (got, model) for f in range(F)]).reshape(2, F)
+        undecoded = want[2] > 0
+        print("(3,6) n = 64800 at %.2f dB, %s: %d of %d frames undecoded in the oracle; triples that differ from it: GPU %d, "
+              "its float model %d" % (ebn0, dec.last_decode_kernel(), int(undecoded.sum()), F, int(differ[0].sum()),
+                                      int(differ[1].sum())))
+        assert undecoded.any()
+        assert not (differ[0] & ~undecoded).any(), "a frame the oracle decodes differs"
+        assert differ[0].sum() <= 1.5 * differ[1].sum() + 1
 
 
 def test_config5_dvbs2_shaped_code_small_batches(pkg, oracle):
