@@ -315,6 +315,10 @@ def main(argv=None):
                     help="a decoder option for A/B measurements (ldpc_amd_set_option), e.g. --opt lds_frames=2")
     ap.add_argument("--no-config-legs", action="store_true",
                     help="skip the short measurements of the other configurations (C1, C4, C5; N=1 only)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="every rank decodes on GPU 0 and the counters are all-reduced over gloo: a rehearsal of the multi-rank "
+                         "path (sharding by global frame index, barriers, maximum over ranks, one JSON line) on a one-GPU box; "
+                         "its rates mean nothing")
     ap.add_argument("--plumbing-test", action="store_true",
                     help="no GPU: gloo backend, CPU tensors and a stand-in decoder; rehearses the stepping, the "
                          "all-reduce, the timing over ranks and the JSON line (tests/test_abi_and_host.py)")
@@ -341,13 +345,15 @@ def main(argv=None):
         dev = torch.device("cpu")
         sync = lambda: None
     else:
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         sync = torch.cuda.synchronize
     # LDPC_BENCH_FORCE_DIST=1 initialises the process group also for a single rank (to rehearse the RCCL path)
     use_dist = world > 1 or (os.environ.get("LDPC_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
     if use_dist:
-        if plumbing:
+        if plumbing or args.rehearse_on_one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -478,7 +484,8 @@ def main(argv=None):
                         "%d frames per GPU per step, BPSK/AWGN Eb/N0=%.1f dB LLRs generated on device (Philox4x32-10), "
                         "all-zero codeword" % (n, iters, F, args.ebn0),
             "frames_per_gpu": F, "iterations": iters, "n": n, "m": m, "edges": int(dec.E),
-            "parallelism": "frames sharded, %d rank(s), counters all-reduced" % world,
+            "parallelism": "frames sharded, %d rank(s), counters all-reduced" % world
+                           + (" (REHEARSAL: all ranks on one GPU, gloo; rates meaningless)" if args.rehearse_on_one_gpu else ""),
         },
         "roofline": roofline,
         "frame_error_rate": float(cnt[1]) / max(float(cnt[0]), 1.0),
