@@ -62,7 +62,8 @@ def simulate_until(simulate_fn, max_iters, min_frame_errors=100, max_frames=10 *
         never leave the device: the batch's vector is all-reduced in place, added to the running total there,
         and one word (the frame errors so far) is read back per batch for the stop rule.
     A caller that wants a rank's share to stay large as ranks are added scales `batch` itself (tools/run_c3_sweep.py
-    uses world x 2^20)."""
+    uses world x 2^20).  The all-reduce is stream-ordered with RCCL (backend "nccl"); with the gloo backend and
+    device tensors let accumulate_fn wait for the device before it returns."""
     if accumulate_fn is None:
         total = np.zeros(capi.CNT_FIXED + int(max_iters), np.uint64)
         done = 0

@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--points", default="0,0.5,1,1.5,2,2.5,3,3.5,4")
     ap.add_argument("--seed", type=int, default=0x5EED)
     ap.add_argument("--zero-codeword", action="store_true", help="send the all-zero word instead of u * encodedG")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="every rank on GPU 0, counters all-reduced over gloo: the multi-rank procedure on a one-GPU box "
+                         "(with --batch fixed, the counts must equal a one-rank run's; the rates mean nothing)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03", "c3_sweep"))
     args = ap.parse_args()
 
@@ -56,10 +59,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     m, n, rows, cols = L.codes.regular_ldpc(4096, 3, 6, seed=1)
     if args.zero_codeword:
@@ -80,8 +88,17 @@ def main():
         t0 = time.perf_counter()
         # the counters stay on the device: one in-place all-reduce and one word read back per batch
         acc = None if args.host_counters else L.sim.device_accumulator(dec, L.capi.CH_AWGN, ebn0, args.seed, args.iters, True)
+        if acc is not None and args.rehearse_on_one_gpu:
+            # gloo with device tensors: the leg is waited for before the all-reduce is issued (issued while the legs of
+            # two ranks were still running on the one GPU, c10d's gloo path never returned)
+            inner = acc
+
+            def acc(first, count, tensor, inner=inner):
+                inner(first, count, tensor)
+                torch.cuda.synchronize()
         c = L.sim.simulate_until(fn, args.iters, min_frame_errors=args.min_errors, max_frames=args.budget,
-                                 batch=batch, rank=rank, world=world, device=dev, accumulate_fn=acc)
+                                 batch=batch, rank=rank, world=world, accumulate_fn=acc,
+                                 device=None if (args.rehearse_on_one_gpu and acc is None) else dev)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         r = L.sim.rates(c, m, n)
