@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LDPC_AMD_VERSION 120 /* 0.1.20 */
+#define LDPC_AMD_VERSION 121 /* 0.1.20 */
 
 /* error codes */
 #define LDPC_AMD_OK 0
@@ -153,6 +153,9 @@ int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
 #define LDPC_AMD_OPT_TUNE_NODES_FLAT_BARRIER 114 /* node-parallel kernel: 1 = every grid barrier is the one-level one (each workgroup
                                                 releases and arrives at one counter); 0 (default) = workgroups meet per XCD first.
                                                 Same results; the A/B also checks the two-level barrier's visibility assumptions */
+#define LDPC_AMD_OPT_TUNE_SMALL_CALL_KB 115   /* host-pointer entry points: calls that move at most this many KiB in and out together run
+                                                on a page-locked staging area that the kernels read and write in place (one launch and
+                                                one wait instead of four copies); 0 (default) = 256, -1 = never, at most 4096 */
 #define LDPC_AMD_OPT_TEST_NODES_OVERSIZE 190 /* tests: ask for a cooperative grid the runtime must refuse */
 #define LDPC_AMD_OPT_TEST_NODES_TIMEOUT 191  /* tests: start the node-parallel kernel with its barrier time-out flag raised */
 /* read-only */

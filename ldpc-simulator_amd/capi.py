@@ -26,7 +26,7 @@ CNT_FIXED = 16
 OPT = {
     "engine": 1, "stream_kernel": 2, "nodes": 3, "sim_overlap": 4, "verbose": 5, "sim_fused": 6,
     "lds_wpe": 100, "lds_fpw": 101, "generic_lds_kb": 102, "nodes_blocks": 103, "fpl": 104, "layout": 105,
-    "rows_waves": 106, "wps": 107, "nopipe": 108, "rows_fused": 109, "generic_threads": 110, "lds_vpt": 111, "rows_leaves": 112, "sim_chunk_mb": 113, "nodes_flat_barrier": 114,
+    "rows_waves": 106, "wps": 107, "nopipe": 108, "rows_fused": 109, "generic_threads": 110, "lds_vpt": 111, "rows_leaves": 112, "sim_chunk_mb": 113, "nodes_flat_barrier": 114, "small_call_kb": 115,
     "test_nodes_oversize": 190, "test_nodes_timeout": 191,
     "nodes_refusals": 200, "nodes_last_hip_error": 201, "noalloc_max_frames": 202, "nodes_barrier_timed_out": 203,
 }

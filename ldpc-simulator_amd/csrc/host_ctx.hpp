@@ -40,6 +40,7 @@ struct Options {
     int lds_wpe = 0, lds_fpw = 0, generic_lds_kb = 0, nodes_blocks = 0, fpl = 0, layout = 0, rows_waves = 0, wps = 0,
         nopipe = 0, rows_fused = -1, generic_threads = 0, lds_vpt = 0;
     int test_nodes_oversize = 0, test_nodes_timeout = 0, nodes_flat = 0;
+    int small_call_kb = 0;
 };
 
 }  // namespace host
@@ -72,6 +73,10 @@ struct ldpc_amd_ctx {
     // (slots 4..7 are the second set of the double-buffered host-pointer path)
     void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t stage_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // page-locked host memory the device reads and writes in place: small host-pointer calls (LDPC_AMD_OPT_TUNE_SMALL_CALL_KB)
+    void* small_host = nullptr;
+    void* small_dev = nullptr;  // the same memory as the device addresses it
+    size_t small_bytes = 0;
     hipStream_t io_stream[2] = {nullptr, nullptr};
     hipEvent_t io_decoded[2] = {nullptr, nullptr};
     hipEvent_t sim_enter = nullptr;  // ldpc_amd_simulate_dev: the caller's stream at the time of the call

@@ -166,6 +166,7 @@ int ldpc_amd_destroy(ldpc_amd_ctx* c) {
             if (c->io_decoded[i]) (void)hipEventDestroy(c->io_decoded[i]);
         }
         if (c->sim_enter) (void)hipEventDestroy(c->sim_enter);
+        if (c->small_host) (void)hipHostFree(c->small_host);
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -240,6 +241,7 @@ int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: if (!range(0, 1)) break; o.test_nodes_oversize = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TEST_NODES_TIMEOUT: if (!range(0, 1)) break; o.test_nodes_timeout = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_NODES_FLAT_BARRIER: if (!range(0, 1)) break; o.nodes_flat = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_SMALL_CALL_KB: if (!range(-1, 4096)) break; o.small_call_kb = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_NODES_REFUSALS:
         case LDPC_AMD_OPT_NODES_LAST_HIP_ERROR:
         case LDPC_AMD_OPT_NOALLOC_MAX_FRAMES:
@@ -277,6 +279,7 @@ int ldpc_amd_get_option(const ldpc_amd_ctx* c, int32_t key, int64_t* value) {
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: *value = o.test_nodes_oversize; break;
         case LDPC_AMD_OPT_TEST_NODES_TIMEOUT: *value = o.test_nodes_timeout; break;
         case LDPC_AMD_OPT_TUNE_NODES_FLAT_BARRIER: *value = o.nodes_flat; break;
+        case LDPC_AMD_OPT_TUNE_SMALL_CALL_KB: *value = o.small_call_kb; break;
         case LDPC_AMD_OPT_NODES_BARRIER_TIMED_OUT: {
             // the flag of the most recent node-parallel launch; the caller has synchronised the stream it ran on
             *value = 0;
@@ -354,6 +357,43 @@ static int decode_host(ldpc_amd_ctx* c, const void* in, size_t in_elem, bool bsc
         if (!c->io_decoded[i]) LDPC_HIP(c, hipEventCreateWithFlags(&c->io_decoded[i], hipEventDisableTiming));
     }
     const size_t n = (size_t)c->n;
+    // A small call (the reference's drivers decode one received word per call, LDPC_GallagerIntStreamSimu.java:122):
+    // four copies and their waits would cost more than the decode.  The words go through page-locked host memory
+    // that the kernels read and write in place: a memcpy in, the launches, one wait, a memcpy out.
+    {
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t in_bytes = (size_t)frames * n * in_elem, o_hard = up(in_bytes), o_it = o_hard + up((size_t)frames * n),
+                     o_sw = o_it + up((size_t)frames * 4), total = o_sw + up((size_t)frames * 4);
+        const size_t limit = c->opt.small_call_kb < 0 ? 0 : (size_t)(c->opt.small_call_kb ? c->opt.small_call_kb : 256) << 10;
+        if (total <= limit) {
+            if (c->small_bytes < total) {
+                if (c->small_host) {
+                    LDPC_HIP(c, hipStreamSynchronize(c->io_stream[0]));
+                    LDPC_HIP(c, hipHostFree(c->small_host));
+                    c->small_host = c->small_dev = nullptr;
+                    c->small_bytes = 0;
+                }
+                const size_t want = std::max(total, (size_t)64 << 10);
+                LDPC_HIP(c, hipHostMalloc(&c->small_host, want, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+                LDPC_HIP(c, hipHostGetDevicePointer(&c->small_dev, c->small_host, 0));
+                c->small_bytes = want;
+            }
+            char* hs = (char*)c->small_host;
+            char* ds = (char*)c->small_dev;
+            memcpy(hs, in, in_bytes);
+            hipStream_t s = c->io_stream[0];
+            SrcArgs src{bsc ? Src::Bsc : Src::Float, (const float*)ds, (const uint8_t*)ds, l0, l1};
+            if (int rc = decode_dev(c, src, frames, max_iters, early_term, (uint8_t*)(ds + o_hard), (int32_t*)(ds + o_it),
+                                    (int32_t*)(ds + o_sw), s))
+                return rc;
+            LDPC_HIP(c, hipStreamSynchronize(s));
+            if (int rc = check_nodes_barrier(c)) return rc;
+            memcpy(hard, hs + o_hard, (size_t)frames * n);
+            if (iters) memcpy(iters, hs + o_it, (size_t)frames * 4);
+            if (synd) memcpy(synd, hs + o_sw, (size_t)frames * 4);
+            return LDPC_AMD_OK;
+        }
+    }
     // about 64 MiB of input per chunk: long enough to keep the link busy, short enough to overlap
     const long long chunk = std::max<long long>(256, (long long)((64ull << 20) / (n * in_elem)));
     const long long chunks = (frames + chunk - 1) / chunk;
