@@ -23,7 +23,7 @@ def test_small_calls_equal_staged_calls_on_every_engine(pkg, oracle):
     cases = (("bp_lds_kernel", pkg.codes.gallager(1024, 8, 2, seed=1), 3.0, {}),
              ("bp_lds_gen_kernel", pkg.codes.nr_bg1_shaped(8, 3)[1], 2.5, {}),
              ("rows_cn_kernel", pkg.codes.regular_ldpc(1536, 3, 6, seed=2), 2.0, {"engine": "stream", "nodes": 0}),
-             ("bp_nodes_kernel", pkg.codes.regular_ldpc(1536, 3, 6, seed=2), 2.0, {"engine": "stream", "nodes": 1}))
+             ("bp_nodes_kernel", pkg.codes.nr_bg1_shaped(8, 3)[1], 2.5, {"generic_lds_kb": -1, "nodes": 1}))
     for name, (m, n, rows, cols), ebn0, options in cases:
         dec = pkg.Decoder(m, n, rows, cols)
         for k, v in options.items():
