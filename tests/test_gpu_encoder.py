@@ -153,8 +153,13 @@ def test_accounting_inside_the_resident_kernels_equals_the_counting_pass(pkg, or
         r, c = np.nonzero(eh)
         dec = pkg.Decoder(m, n, r.astype(np.int32), c.astype(np.int32))
         g = oracle.Graph(m, n, r, c)
-        for with_g in (False, True):
-            dec.set_generator(eg if with_g else None)
+        # "wrong": a generator whose rows are not codewords of this H (nothing checks that they are): the transmitted
+        # words then have a non-zero syndrome, no frame can be decoded to them, and the fused leg must still count
+        # exactly what the two-pass leg and the checker count.
+        wrong = eg.copy()
+        wrong[::3, n - m + 5] ^= 1
+        for with_g in (False, True, "wrong"):
+            dec.set_generator(wrong if with_g == "wrong" else eg if with_g else None)
             for early in early_cases:
                 for ch, param, frames, L in ((oracle.CH_BSC_INFO, 0.03, 1000, 30), (oracle.CH_BSC_ALL, 0.04, 777, 20),
                                              (oracle.CH_AWGN, 2.0, 1501, 25), (oracle.CH_AWGN, 4.5, 64, 10)):
@@ -172,7 +177,7 @@ def test_accounting_inside_the_resident_kernels_equals_the_counting_pass(pkg, or
                     # (the (8,2) code only: on the (6,3) code one frame in a thousand takes an iteration more or less in
                     # fp32 than in the checker's double, with either leg)
                     if ch != oracle.CH_AWGN and early and dc == 8:
-                        want = g.simulate(ch, param, 17, 123, frames, L, G=eg if with_g else None)
+                        want = g.simulate(ch, param, 17, 123, frames, L, G=wrong if with_g == "wrong" else eg if with_g else None)
                         assert (ref == want).all(), (shape, with_g, ch, ref[:12], want[:12])
         # no frames, and a rule the fused kernels are not built for: the counting pass takes over
         dec.set_option("sim_fused", 1)
