@@ -123,12 +123,12 @@ __global__ void __launch_bounds__(256) gen_awgn_kernel(int n, float a, float b, 
     for (int h = 0; h < 2; ++h) {
         const float u1 = ((float)xs[2 * h] + 0.5f) * 2.3283064365386963e-10f;
         const float u2 = (float)xs[2 * h + 1] * 2.3283064365386963e-10f;
-        const float rad = sqrtf(-2.0f * logf(u1));
-        const float th = 6.283185307179586f * u2;
-        float sn, cs;
-        sincosf(th, &sn, &cs);   // one argument reduction for both; the same values as sinf and cosf
-        z[2 * h] = rad * cs;
-        z[2 * h + 1] = rad * sn;
+        // the hardware's own log2, square root, sine and cosine (the last two take their argument in revolutions, which
+        // is what u2 is): about 1e-6 of relative error in z, a quarter of the instructions of the library functions
+        // (with those this kernel was bound by their arithmetic, at a third of the rate the LLR stores allow)
+        const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
+        z[2 * h] = rad * __builtin_amdgcn_cosf(u2);
+        z[2 * h + 1] = rad * __builtin_amdgcn_sinf(u2);
     }
     // bit 0 is sent as +1, bit 1 as -1: llr = 2 y / sigma^2 with y = (1 - 2c) + sigma z
     float v[4];
