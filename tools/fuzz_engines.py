@@ -63,6 +63,8 @@ def fuzz(cases, seed):
     bad = 0
     seen = {}
     for c in range(cases):
+        if c and c % 250 == 0:
+            print("... %d cases, %d mismatches so far" % (c, bad), file=sys.stderr, flush=True)
         m, n, rows, cols = random_code(rng)
         if len(rows) == 0:
             continue
