@@ -154,8 +154,9 @@ int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
                                                 releases and arrives at one counter); 0 (default) = workgroups meet per XCD first.
                                                 Same results; the A/B also checks the two-level barrier's visibility assumptions */
 #define LDPC_AMD_OPT_TUNE_SMALL_CALL_KB 115   /* host-pointer entry points: calls that move at most this many KiB in and out together run
-                                                on a page-locked staging area that the kernels read and write in place (one launch and
-                                                one wait instead of four copies); 0 (default) = 256, -1 = never, at most 4096 */
+                                                on a page-locked staging area of the context that the kernels read and write in place
+                                                (one launch and one wait instead of four copies); 0 (default) = 1024, and 32768 when the
+                                                caller's input is pageable memory; -1 = never; at most 65536 */
 #define LDPC_AMD_OPT_TEST_NODES_OVERSIZE 190 /* tests: ask for a cooperative grid the runtime must refuse */
 #define LDPC_AMD_OPT_TEST_NODES_TIMEOUT 191  /* tests: start the node-parallel kernel with its barrier time-out flag raised */
 /* read-only */

@@ -241,7 +241,7 @@ int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: if (!range(0, 1)) break; o.test_nodes_oversize = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TEST_NODES_TIMEOUT: if (!range(0, 1)) break; o.test_nodes_timeout = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_NODES_FLAT_BARRIER: if (!range(0, 1)) break; o.nodes_flat = v; return LDPC_AMD_OK;
-        case LDPC_AMD_OPT_TUNE_SMALL_CALL_KB: if (!range(-1, 4096)) break; o.small_call_kb = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_SMALL_CALL_KB: if (!range(-1, 65536)) break; o.small_call_kb = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_NODES_REFUSALS:
         case LDPC_AMD_OPT_NODES_LAST_HIP_ERROR:
         case LDPC_AMD_OPT_NOALLOC_MAX_FRAMES:
@@ -364,7 +364,19 @@ static int decode_host(ldpc_amd_ctx* c, const void* in, size_t in_elem, bool bsc
         auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t in_bytes = (size_t)frames * n * in_elem, o_hard = up(in_bytes), o_it = o_hard + up((size_t)frames * n),
                      o_sw = o_it + up((size_t)frames * 4), total = o_sw + up((size_t)frames * 4);
-        const size_t limit = c->opt.small_call_kb < 0 ? 0 : (size_t)(c->opt.small_call_kb ? c->opt.small_call_kb : 256) << 10;
+        // Measured on the reference's default code (tools/perf_per_call.py): from page-locked caller memory this route
+        // wins up to about 1 MiB (512 words: 141 -> 120 us; 2048 words: 243 -> 287 us), from pageable memory, whose
+        // staged copies the runtime bounces through buffers of its own, at every size tried (33 MiB: 1.91 -> 1.43 ms).
+        size_t limit = c->opt.small_call_kb < 0 ? 0 : (size_t)c->opt.small_call_kb << 10;
+        if (c->opt.small_call_kb == 0) {
+            limit = (size_t)1 << 20;
+            if (total > limit && total <= ((size_t)32 << 20)) {
+                hipPointerAttribute_t attr{};
+                const hipError_t pe = hipPointerGetAttributes(&attr, in);
+                if (pe != hipSuccess) (void)hipGetLastError();  // memory the runtime has never seen: pageable
+                if (pe != hipSuccess || attr.type == hipMemoryTypeUnregistered) limit = (size_t)32 << 20;
+            }
+        }
         if (total <= limit) {
             if (c->small_bytes < total) {
                 if (c->small_host) {

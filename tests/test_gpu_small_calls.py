@@ -46,17 +46,31 @@ def test_small_call_limit_and_growth_of_the_staging_area(pkg, oracle):
     dec = pkg.Decoder(m, n, rows, cols)
     g = oracle.Graph(m, n, rows, cols)
     per_frame = n * 4 + n + 8                      # bytes in and out of one frame of float LLRs
-    at_limit = (256 << 10) // per_frame            # the default limit is 256 KiB, every array rounded up to 256 bytes
+    at_limit = (256 << 10) // per_frame            # frames that fit a limit of 256 KiB (every array rounded up to 256 bytes)
     results = {}
-    # 1 frame (64 KiB area), then more than 64 KiB (the area grows), then around the limit, then a larger limit
-    for F, kb in ((1, 0), (40, 0), (at_limit - 2, 0), (at_limit + 2, 0), (at_limit + 2, 1024), (3, 0), (700, 4096)):
+    # 1 frame (64 KiB area), then more than 64 KiB (the area grows), then around an explicit limit, a larger limit, a
+    # small call again, and the library's own choice for a batch of 3.5 MiB from pageable memory
+    for F, kb in ((1, 0), (40, 0), (at_limit - 2, 256), (at_limit + 2, 256), (at_limit + 2, 1024), (3, 0), (700, 4096), (700, 0)):
         dec.set_option("small_call_kb", kb)
         llr = oracle.gen_awgn_llr(m, n, 3.5, seed=23, first_frame=0, frames=F)
         got = dec.decode_batch(llr, 15, True)
         want = g.decode_llr_batch(llr, 15, True)
         assert all(np.array_equal(x, y) for x, y in zip(got, want)), (F, kb)
         results[(F, kb)] = got
-    assert all(np.array_equal(x, y) for x, y in zip(results[(at_limit + 2, 0)], results[(at_limit + 2, 1024)]))
+    assert all(np.array_equal(x, y) for x, y in zip(results[(at_limit + 2, 256)], results[(at_limit + 2, 1024)]))
+    # page-locked caller buffers (the library then keeps the in-place route to calls of at most 1 MiB): both sides of it
+    for F in (100, 400):
+        bufs = [pkg.capi.HostBuffer((F, n), np.float32), pkg.capi.HostBuffer((F, n), np.uint8),
+                pkg.capi.HostBuffer((F,), np.int32), pkg.capi.HostBuffer((F,), np.int32)]
+        bufs[0].array[:] = oracle.gen_awgn_llr(m, n, 3.5, seed=29, first_frame=0, frames=F)
+        dec.set_option("small_call_kb", 0)
+        ptr = pkg.capi._np_ptr
+        rc = dec._lib.ldpc_amd_decode_batch(dec._h, ptr(bufs[0].array), F, 15, 1, ptr(bufs[1].array), ptr(bufs[2].array), ptr(bufs[3].array))
+        assert rc == 0
+        want = g.decode_llr_batch(bufs[0].array, 15, True)
+        assert all(np.array_equal(x, y.array) for x, y in zip(want, bufs[1:])), F
+        for b in bufs:
+            b.close()
     with pytest.raises(pkg.LdpcError):
-        dec.set_option("small_call_kb", 4097)
+        dec.set_option("small_call_kb", 65537)
     dec.close()

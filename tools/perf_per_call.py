@@ -52,7 +52,7 @@ def bench_calls(dec, F, seconds=1.0, pinned=False):
 dec = L.Decoder(m, n, rows, cols)
 print("BSC e = %g, small_call_kb = %d" % (E_RATE, SMALL_KB))
 print("one thread, frames per call -> calls/s, frames/s, us per call (mean iterations), pageable | page-locked buffers")
-for F in (1, 8, 64, 512, 4096):
+for F in (1, 8, 64, 512, 2048, 4096, 16384):
     a, mi = bench_calls(dec, F)
     b, _ = bench_calls(dec, F, pinned=True)
     print("  %5d frames per call: %9.0f calls/s %11.0f frames/s %8.1f us (%.1f it) | %9.0f calls/s %11.0f frames/s %8.1f us  [%s]" % (
