@@ -75,6 +75,25 @@ __device__ __forceinline__ uint32_t lds_address(const void* generic) {
 __device__ __forceinline__ float lds_load(uint32_t a) { return *(const lds_float*)(uintptr_t)a; }
 __device__ __forceinline__ void lds_store(uint32_t a, float v) { *(lds_float*)(uintptr_t)a = v; }
 
+// byte offset x of a message slot -> its pair row: x / (4 * lds_pair_stride(dc)) == (x * magic) >> 22 for every slot of a
+// code these kernels take (at most 1024 pair rows), the product below 2^32
+__host__ __device__ constexpr uint32_t pair_row_magic(int dc) {
+    return ((1u << 22) + 4u * (uint32_t)lds_pair_stride(dc) - 1u) / (4u * (uint32_t)lds_pair_stride(dc));
+}
+__host__ __device__ constexpr bool pair_row_magic_exact(int dc) {
+    // both sides are non-decreasing in x, and x / bytes steps only at the multiples of `bytes`: looking at each
+    // multiple and at its predecessor covers every x
+    const uint32_t bytes = 4u * (uint32_t)lds_pair_stride(dc), magic = pair_row_magic(dc);
+    for (uint32_t row = 1; row <= 1024u; ++row) {
+        const uint32_t x = row * bytes;
+        if (((x - 1u) * magic) >> 22 != row - 1u) return false;
+        if (row < 1024u && (x * magic) >> 22 != row) return false;
+    }
+    return (unsigned long long)(1024u * bytes - 1u) * magic < (1ull << 32) && magic < (1u << 24);
+}
+template <int DC> constexpr uint32_t kPairRowMagic = pair_row_magic(DC);
+static_assert(pair_row_magic_exact(6) && pair_row_magic_exact(8) && pair_row_magic_exact(10), "slot -> pair row by multiplication");
+
 template <int V> struct LdsInt { static constexpr int value = V; };
 struct LdsYes { static constexpr bool value = true; };
 struct LdsNo { static constexpr bool value = false; };
@@ -269,8 +288,10 @@ __global__ void __launch_bounds__(4096 / VPT, WPE) bp_lds_kernel(LdsParams p) {
                 // one-to-one numbering of the checks serves
                 uint32_t o = off[v][k];
                 asm volatile("" : "+v"(o));  // formed here, when needed: 24 more loop invariants do not fit
-                const uint32_t slot = (o - lds_base) >> 2;
-                const uint32_t b = 2u * (slot / (uint32_t)lds_pair_stride(DC)) + (slot & 1u);
+                // byte offset / (bytes of a pair row) by a 24-bit multiplication (full rate; the 32-bit division the
+                // compiler forms takes a quarter-rate v_mul_hi_u32 per edge)
+                const uint32_t x = o - lds_base;
+                const uint32_t b = 2u * ((uint32_t)__umul24(x, kPairRowMagic<DC>) >> 22) + ((x >> 2) & 1u);
                 if constexpr (DEF) {
                     if (k == DV - 1 && is_short(v)) continue;  // the extra edge is not an edge of the code
                 }
