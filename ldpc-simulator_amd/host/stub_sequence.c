@@ -1,5 +1,5 @@
 /*
- * The native calls of the Java binding of LogDecoder.decode (the stub in INTEGRATION.md), in its order, from C:
+ * The native calls of a Java (Panama FFM) binding of LogDecoder.decode, in its order, from C:
  * what a JVM caller does to the library over a run of the reference's driver
  * (LDPC_GallagerIntStreamSimu.java:55-76, :122).
  *

@@ -61,7 +61,7 @@ def test_load_int_stream(pkg, tmp_path):
 
 
 def test_the_java_stubs_call_sequence_through_the_c_abi(tmp_path, pkg):
-    """host/stub_sequence.c makes the native calls of the Java binding of LogDecoder.decode in its
+    """host/stub_sequence.c makes the native calls of a Java (Panama FFM) binding of LogDecoder.decode in their
     order: contexts in a least-recently-used cache of four (a fifth matrix destroys the oldest), page-locked
     frame buffers allocated once and reused, ldpc_amd_decode_bsc_batch per batch (LogDecoder.java:15-17, callers
     LDPC_GallagerIntStreamSimu.java:55-76, :122).  Every call's outputs must equal the same call through the

@@ -1,6 +1,6 @@
 // Issue rates of the vector instructions the check-node rule is made of, on MI355X (gfx950): SIMD cycles
 // per wave64 instruction at 1 .. 8 waves per SIMD, every CU busy.  These set the VALU-issue ceiling of the
-// frame-resident decoder kernel (bench.py, DESIGN.md).
+// frame-resident decoder kernel (bench.py).
 // Build: hipcc -O3 --offload-arch=gfx950 -o tools/valu_rates tools/valu_rates.hip
 // Each wave runs REPS x 16 independent instructions of one kind (16 registers, each instruction depends only
 // on the one 16 earlier) between two s_memtime stamps; a workgroup is 4 waves (one per SIMD), k workgroups
