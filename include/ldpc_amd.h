@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LDPC_AMD_VERSION 121 /* 0.1.20 */
+#define LDPC_AMD_VERSION 121 /* 0.1.21 */
 
 /* error codes */
 #define LDPC_AMD_OK 0
