@@ -206,8 +206,8 @@ int ldpc_amd_decode_batch_dev(ldpc_amd_ctx* ctx, const float* d_llr, int64_t fra
 
 /*
  * ldpc_amd_decode_batch_dev for callers that cannot allocate device memory while they decode: tight
- * serving loops, harnesses that forbid hipMalloc, code that must not wait for the allocator (it has not been run
- * under HIP graph capture).  It has no counterpart in the
+ * serving loops, harnesses that forbid hipMalloc, code under HIP graph capture (a call captured on a stream
+ * replays on whatever the captured buffers hold then; the first call of a process is made outside a capture).  It has no counterpart in the
  * reference (whose decode() allocates all of its state per call, LogDecoder.java:57-58).  Same arguments,
  * same outputs bit for bit; it calls no hipMalloc / hipFree or other allocating routine.  The frame-major
  * message, LLR, decision and per-frame state arrays of the sweep kernels ("rows_cn_kernel"), which the

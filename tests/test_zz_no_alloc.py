@@ -69,3 +69,38 @@ def test_no_alloc_entry_point_equals_decode_batch_dev(pkg):
     want, got = _pair(dec, torch, 2.0, 12, 130, 15, False)
     _same(want, got, "irregular code, min-sum")
     dec.close()
+
+
+def test_no_alloc_entry_point_under_graph_capture(pkg):
+    """The callers the entry point is for include code under HIP graph capture: the call is captured into a graph
+    (torch.cuda.graph on a side stream), then replayed three times on new LLRs written into the captured buffers;
+    every replay must return what ldpc_amd_decode_batch_dev returns for those LLRs."""
+    import torch
+    m, n, rows, cols = pkg.codes.regular_ldpc(4096, 3, 6, seed=1)
+    dec = pkg.Decoder(m, n, rows, cols)
+    F, L = 777, 25
+    d_llr = torch.empty((F, n), dtype=torch.float32, device="cuda")
+    d_hard = torch.full((F, n), 9, dtype=torch.uint8, device="cuda")
+    d_it = torch.full((F,), -7, dtype=torch.int32, device="cuda")
+    d_sw = torch.full((F,), -7, dtype=torch.int32, device="cuda")
+    dec.gen_awgn_llr_dev(1.8, 3, 0, F, d_llr.data_ptr())
+    # once outside any capture: module loading, function attributes
+    dec.decode_batch_dev_noalloc(d_llr.data_ptr(), F, L, True, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr())
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        dec.decode_batch_dev_noalloc(d_llr.data_ptr(), F, L, True, d_hard.data_ptr(), d_it.data_ptr(), d_sw.data_ptr(), s.cuda_stream)
+    for ebn0, seed in ((1.8, 3), (2.4, 4), (1.2, 5)):
+        dec.gen_awgn_llr_dev(ebn0, seed, 0, F, d_llr.data_ptr())      # new inputs in the captured buffers
+        d_hard.fill_(9); d_it.fill_(-7); d_sw.fill_(-7)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        got = (d_hard.cpu().numpy(), d_it.cpu().numpy(), d_sw.cpu().numpy())
+        h2 = torch.empty_like(d_hard); i2 = torch.empty_like(d_it); w2 = torch.empty_like(d_sw)
+        dec.decode_batch_dev(d_llr.data_ptr(), F, L, True, h2.data_ptr(), i2.data_ptr(), w2.data_ptr())
+        torch.cuda.synchronize()
+        for a, b in zip(got, (h2.cpu().numpy(), i2.cpu().numpy(), w2.cpu().numpy())):
+            assert np.array_equal(a, b), (ebn0, seed)
+    dec.close()
