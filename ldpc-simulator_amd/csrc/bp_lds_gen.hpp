@@ -2,20 +2,19 @@
 // decodes one frame; its messages, the channel LLRs and the packed decisions stay in LDS for all
 // iterations (see bp_lds.hpp for the specialised regular-code version of the same idea).
 //
-// Message slots: the 128 checks that one wave handles in one step (64 lanes x 2 checks) form a block
-// laid out as [position in the row][check 0/1 of the lane][lane], so every check-node access of a
-// wave is 64 consecutive words (no bank conflict, whatever the degree); a block is as deep as its
-// largest degree.  The variable side reaches its messages through a slot table in place of CSR edge
-// ids.
+// Message slots: the row of a check is contiguous, and the rows of the lanes that run one degree's code together
+// follow each other with a word of skew wherever their banks would repeat, so a check-node access of a wave
+// meets no bank conflict, whatever the degree, at constant offsets from the row's first slot.
+// The variable side reaches its messages through a slot table in place of CSR edge ids.
 //
-// Degrees are per node here.  The host sorts checks and variables by degree and deals them out in
-// that order, two neighbours of the sorted list at a time, to the work items t + u * nt (thread t,
-// step u): the 64 lanes of a wave at one step hold nodes of (nearly) one degree, so the per-degree
-// code runs with little divergence, and the two nodes of an item nearly always have the same degree,
-// in which case they share packed registers (cn_complement<v2f, D> / vn_compute_v<v2f, D>: the same
-// operations as the scalar code of the streaming engines, hence the same bits).  Items whose two
-// degrees differ, and the other check-node rules, go through cn_dispatch / vn_dispatch one node at a
-// time.  Slots past the last node are marked empty.
+// Degrees are per node here.  The host sorts checks and variables by degree and pairs neighbours of the sorted
+// list into work items, so the two nodes of an item nearly always have the same degree, in which case they share
+// packed registers (cn_complement<v2f, D> / vn_compute_v<v2f, D>: the same operations as the scalar code of the
+// streaming engines, hence the same bits).  Items whose two degrees differ, and the other check-node rules, go
+// through cn_dispatch / vn_dispatch one node at a time.  A wave runs the code of every degree present among its
+// 64 lanes of a step in turn; the host places the items on the slots t + u * nt (thread t, step u) so that each
+// wave meets few degrees and the waves of a workgroup have equal work (build_generic_resident_tables).  Slots
+// past the last node are marked empty.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,12 +27,12 @@ namespace ldpc {
 constexpr int kLdsGenMaxDc = 20, kLdsGenMaxDv = 32;
 // degrees up to which two nodes share packed registers (beyond that the register file does not hold a pair)
 constexpr int kLdsGenPairDc = 10, kLdsGenPairDv = 8;
-constexpr int kGenRowStride = 128;  // words between consecutive positions of a check's row (2 checks x 64 lanes)
+constexpr int kGenRowStride = 1;    // words between consecutive positions of a check's row
 
 struct LdsGenParams {
     int m, n, nwp;          // nwp: words of decisions = 2 * vn_steps * nt / 32
     long long E;
-    int slots;              // message words in LDS (E plus the padding of blocks with mixed degrees)
+    int slots;              // message words in LDS (E plus the words of skew between rows of even degree)
     int cn_steps, vn_steps; // work items (pairs of nodes) per thread
     const int* row_ptr;     // [m+1]
     const int* col_slot;    // [E] message slots of a variable's edges, ascending check (CSC order)

@@ -331,17 +331,155 @@ int build_resident_tables(ldpc_amd_ctx* c, int nt, int vpt) {
     return LDPC_AMD_OK;
 }
 
-// Tables of the generic frame-resident engine: checks and variables sorted by degree (ties in index
-// order); neighbours 2q, 2q+1 of the sorted list form work item q, and the items are dealt out to the
-// slots t + u * nt in that order, so that a wave meets one degree at a time and the two nodes of an
-// item nearly always share a degree.  The decision bit of the variable that is node h of item q sits at
-// position 128 * (q / 64) + 64 * h + q % 64 (one 64-bit ballot per half).
+// Deals the work items of one phase of the generic frame-resident engine out to the lanes of its workgroup.
+// deg[q] = degrees of the two nodes of item q.  A wavefront runs the code of every distinct pair of degrees
+// among its 64 lanes of a step one after the other, so the time of a (step, wavefront) block is about the sum
+// over its distinct pairs of (da + db + overhead), whatever the number of lanes on each, and a phase lasts as
+// long as its slowest wavefront.  Items are grouped by their pair of degrees, cut into chunks of at most 64 and
+// placed, dearest first, on the wavefront with the least time so far (in its emptiest block); a chunk whose pair
+// a block already holds joins it for free.  Returns the slot t + u * nt of every item; *slowest = the modelled
+// time of the slowest wavefront.
+static std::vector<int> deal_items(const std::vector<std::pair<int, int>>& deg, int nt, int steps, int overhead, int* slowest) {
+    const int waves = nt / 64, items = (int)deg.size();
+    struct Chunk { int cost, da, db; std::vector<int> q; };
+    std::vector<Chunk> chunks;
+    {
+        std::vector<int> order((size_t)items);
+        for (int q = 0; q < items; ++q) order[(size_t)q] = q;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            const int ca = deg[(size_t)a].first + deg[(size_t)a].second, cb = deg[(size_t)b].first + deg[(size_t)b].second;
+            if (ca != cb) return ca > cb;
+            return deg[(size_t)a].first > deg[(size_t)b].first;
+        });
+        for (int k = 0; k < items; ++k) {
+            const int q = order[(size_t)k];
+            const int da = deg[(size_t)q].first, db = deg[(size_t)q].second;
+            if (chunks.empty() || chunks.back().da != da || chunks.back().db != db || chunks.back().q.size() == 64)
+                chunks.push_back(Chunk{da + db + overhead, da, db, {}});
+            chunks.back().q.push_back(q);
+        }
+        std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& a, const Chunk& b) {
+            if (a.cost != b.cost) return a.cost > b.cost;
+            return a.q.size() > b.q.size();
+        });
+    }
+    std::vector<int> load((size_t)waves, 0), used((size_t)steps * waves, 0), slot((size_t)items, -1);
+    std::vector<std::vector<std::pair<int, int>>> held((size_t)steps * waves);
+    for (Chunk& ch : chunks) {
+        size_t done = 0;
+        while (done < ch.q.size()) {
+            int blk = -1, add = 0;
+            for (int b = 0; b < steps * waves && blk < 0; ++b)
+                if (used[(size_t)b] < 64)
+                    for (const auto& pr : held[(size_t)b])
+                        if (pr.first == ch.da && pr.second == ch.db) { blk = b; break; }
+            if (blk < 0) {
+                int best_w = -1;
+                for (int w = 0; w < waves; ++w) {
+                    bool room = false;
+                    for (int u = 0; u < steps; ++u) room = room || used[(size_t)(u * waves + w)] < 64;
+                    if (room && (best_w < 0 || load[(size_t)w] < load[(size_t)best_w])) best_w = w;
+                }
+                for (int u = 0; u < steps; ++u) {
+                    const int b = u * waves + best_w;
+                    if (used[(size_t)b] < 64 && (blk < 0 || used[(size_t)b] < used[(size_t)blk])) blk = b;
+                }
+                add = ch.cost;
+                held[(size_t)blk].push_back({ch.da, ch.db});
+            }
+            const int u = blk / waves, w = blk % waves;
+            load[(size_t)w] += add;
+            while (done < ch.q.size() && used[(size_t)blk] < 64) {
+                slot[(size_t)ch.q[done++]] = u * nt + 64 * w + used[(size_t)blk];
+                ++used[(size_t)blk];
+            }
+        }
+    }
+    *slowest = *std::max_element(load.begin(), load.end());
+    return slot;
+}
+
+// Work items of one phase: nodes in descending order of degree (`sorted`, degrees `d`), two nodes of one degree
+// per item.  Packed arithmetic takes as long as the same operations one element at a time, so an item of two
+// nodes costs a wavefront twice the time of an item of one, whatever the number of lanes that hold such items:
+// with `singles`, what is left of a degree after whole wavefronts of pairs (128 nodes) goes one node to a lane
+// when that fits in one wavefront (at most 64 nodes), which halves its time.  Second node -1 = none.
+static std::vector<std::pair<int, int>> form_items(const std::vector<int>& sorted, const std::vector<int>& d, bool singles) {
+    std::vector<std::pair<int, int>> items;
+    const size_t total = sorted.size();
+    for (size_t g0 = 0; g0 < total;) {
+        size_t g1 = g0;
+        while (g1 < total && d[(size_t)sorted[g1]] == d[(size_t)sorted[g0]]) ++g1;
+        const size_t count = g1 - g0, rest = count % 128, paired = (singles && rest <= 64) ? count - rest : count;
+        size_t k = g0;
+        for (; k + 1 < g0 + paired; k += 2) items.push_back({sorted[k], sorted[k + 1]});
+        for (; k < g1; ++k) items.push_back({sorted[k], -1});
+        g0 = g1;
+    }
+    return items;
+}
+
+// One phase's items and their places: both ways of forming the items are dealt out and the one whose slowest
+// wavefront is faster by the model is kept (every step costs each wavefront `step_cost` more: its descriptor
+// reads and branches).  max_steps bounds the steps per thread.
+struct PhasePlan {
+    std::vector<std::pair<int, int>> items;
+    std::vector<int> slot;
+    int steps = 0;
+};
+static PhasePlan plan_phase(const std::vector<int>& sorted, const std::vector<int>& d, int nt, int overhead, int step_cost,
+                            int max_steps) {
+    PhasePlan best;
+    int best_time = 0;
+    for (int singles = 0; singles < 2; ++singles) {
+        PhasePlan p;
+        p.items = form_items(sorted, d, singles != 0);
+        p.steps = ((int)p.items.size() + nt - 1) / nt;
+        if (singles && p.steps > max_steps && !best.items.empty()) continue;
+        std::vector<std::pair<int, int>> deg(p.items.size());
+        for (size_t q = 0; q < p.items.size(); ++q)
+            deg[q] = {d[(size_t)p.items[q].first], p.items[q].second >= 0 ? d[(size_t)p.items[q].second] : 0};
+        int slowest = 0;
+        p.slot = deal_items(deg, nt, p.steps, overhead, &slowest);
+        const int time = slowest + p.steps * step_cost;
+        if (best.items.empty() || time < best_time) {
+            best = std::move(p);
+            best_time = time;
+        }
+    }
+    return best;
+}
+
+// Tables of the generic frame-resident engine.  Checks and variables are sorted by degree (ties in index
+// order) and formed into work items of two nodes of one degree, or of one node (form_items); deal_items places
+// the items on the slots t + u * nt (thread t, step u) so that the wavefronts of a workgroup have equal work.
+// The decision bit of the variable that is node h of the item in slot s sits at position
+// 128 * (s / 64) + 64 * h + s % 64 (one 64-bit ballot per half).
+// Message slots: a check's row is contiguous; the rows of the first checks of a run of lanes with one pair of
+// degrees follow each other, then those of the second checks, with a word of skew wherever the banks would
+// repeat, so the lanes that run one degree's code together meet no bank conflict.
 int build_generic_resident_tables(ldpc_amd_ctx* c, int nt) {
     if (c->d_genres && c->gen_nt == nt) return LDPC_AMD_OK;
     const int m = c->m, n = c->n;
     const long long E = c->E;
-    const int cn_items = (m + 1) / 2, vn_items = (n + 1) / 2;
-    const int cn_steps = (cn_items + nt - 1) / nt, vn_steps = (vn_items + nt - 1) / nt;
+    // model constants, in units of one edge of a node: what a wavefront pays per distinct pair of degrees in a step
+    // and per step (measured flat between 0 and 12 / 24 on NR-BG1-shaped and quasi-cyclic codes)
+    const int overhead_cn = 2, overhead_vn = 12, step_cn = 4, step_vn = 8;
+    std::vector<int> dc((size_t)m), dv((size_t)n), sorted((size_t)m);
+    for (int i = 0; i < m; ++i) {
+        dc[(size_t)i] = c->h_row_ptr[(size_t)i + 1] - c->h_row_ptr[(size_t)i];
+        sorted[(size_t)i] = i;
+    }
+    std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b) { return dc[(size_t)a] > dc[(size_t)b]; });
+    const PhasePlan cn = plan_phase(sorted, dc, nt, overhead_cn, step_cn, 1 << 20);
+    sorted.resize((size_t)n);
+    for (int j = 0; j < n; ++j) {
+        dv[(size_t)j] = c->h_col_ptr[(size_t)j + 1] - c->h_col_ptr[(size_t)j];
+        sorted[(size_t)j] = j;
+    }
+    std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b) { return dv[(size_t)a] > dv[(size_t)b]; });
+    const PhasePlan vn = plan_phase(sorted, dv, nt, overhead_vn, step_vn, 16);  // 2 decision bits per step in one register
+    const int cn_steps = cn.steps, vn_steps = vn.steps;
     // layout: cn_desc int4[cn_steps*nt] | vn_desc int4[vn_steps*nt][2] | pos_of_var[n] | edge_pos[E] | edge_slot[E] |
     //         col_slot[E] | col_check[E]
     std::vector<int> tab((size_t)4 * cn_steps * nt + (size_t)8 * vn_steps * nt + (size_t)n + (size_t)4 * E, 0);
@@ -353,42 +491,72 @@ int build_generic_resident_tables(ldpc_amd_ctx* c, int nt) {
     int* col_slot = edge_slot + E;
     int* col_check = col_slot + E;
     for (int q = 0; q < 2 * vn_steps * nt; ++q) vn_desc[4 * q] = -1;
-    std::vector<int> idx((size_t)std::max(m, n));
-    for (int i = 0; i < m; ++i) idx[(size_t)i] = i;
-    std::stable_sort(idx.begin(), idx.begin() + m, [&](int a, int b) {
-        return c->h_row_ptr[(size_t)a + 1] - c->h_row_ptr[(size_t)a] > c->h_row_ptr[(size_t)b + 1] - c->h_row_ptr[(size_t)b];
-    });
-    // Message slots: block (step u, wave w) holds the 128 checks of that wave's lanes in that step as
-    // [position in the row][check 0/1 of the lane][lane]; sorted descending, the first check of a block
-    // has its largest degree, which is the block's depth.
     int slots = 0;
-    for (int item0 = 0; item0 < cn_items; item0 += 64) {  // items t = 64 w .. 64 w + 63 of step u, in order
-        const int first = idx[(size_t)(2 * item0)];
-        const int depth = c->h_row_ptr[(size_t)first + 1] - c->h_row_ptr[(size_t)first];
-        for (int q = 2 * item0; q < std::min(m, 2 * (item0 + 64)); ++q) {  // node q & 1 of item q >> 1
-            const int i = idx[(size_t)q], lane = (q >> 1) - item0, h = q & 1;
-            const int e0 = c->h_row_ptr[(size_t)i], d = c->h_row_ptr[(size_t)i + 1] - e0;
-            const int s0 = slots + h * 64 + lane;
-            cn_desc[2 * q] = s0;
-            cn_desc[2 * q + 1] = d;
-            for (int k = 0; k < d; ++k) edge_slot[e0 + k] = s0 + k * kGenRowStride;
+    {
+        std::vector<int> item_at((size_t)cn_steps * nt, -1);
+        for (size_t q = 0; q < cn.items.size(); ++q) item_at[(size_t)cn.slot[q]] = (int)q;
+        auto degrees = [&](int q) {
+            const auto& it = cn.items[(size_t)q];
+            return std::make_pair(dc[(size_t)it.first], it.second >= 0 ? dc[(size_t)it.second] : 0);
+        };
+        for (int s0 = 0; s0 < cn_steps * nt;) {
+            const int q0 = item_at[(size_t)s0];
+            if (q0 < 0) { ++s0; continue; }
+            int s1 = s0 + 1;  // run of lanes of one block with one pair of degrees
+            while (s1 < cn_steps * nt && (s1 & 63) != 0 && item_at[(size_t)s1] >= 0 && degrees(item_at[(size_t)s1]) == degrees(q0)) ++s1;
+            const int run = s1 - s0, da = degrees(q0).first, db = degrees(q0).second;
+            // row r of a region of rows of degree d starts r * d + r / (32 / gcd(d, 32)) words into it: a 4-byte
+            // access of a wavefront is served 32 lanes at a time from 32 banks, rows d words apart repeat their
+            // banks every 32 / gcd rows, and one word of skew there gives 32 lanes 32 different banks
+            auto skew_rows = [](int d) { int g = 1; while (g < 32 && d % (2 * g) == 0) g *= 2; return 32 / g; };
+            auto row_at = [&](int r, int d) { return r * d + r / skew_rows(d); };
+            const int size_a = da ? row_at(run - 1, da) + da : 0, size_b = db ? row_at(run - 1, db) + db : 0;
+            for (int s = s0; s < s1; ++s) {
+                const auto& it = cn.items[(size_t)item_at[(size_t)s]];
+                for (int h = 0; h < 2; ++h) {
+                    const int i = h ? it.second : it.first;
+                    if (i < 0) continue;
+                    const int e0 = c->h_row_ptr[(size_t)i], d = h ? db : da;
+                    const int first = h ? slots + size_a + row_at(s - s0, db) : slots + row_at(s - s0, da);
+                    cn_desc[4 * s + 2 * h] = first;
+                    cn_desc[4 * s + 2 * h + 1] = d;
+                    for (int k = 0; k < d; ++k) edge_slot[e0 + k] = first + k * kGenRowStride;
+                }
+            }
+            slots += size_a + size_b;
+            s0 = s1;
         }
-        slots += depth * kGenRowStride;
     }
-    for (int j = 0; j < n; ++j) idx[(size_t)j] = j;
-    std::stable_sort(idx.begin(), idx.begin() + n, [&](int a, int b) {
-        return c->h_col_ptr[(size_t)a + 1] - c->h_col_ptr[(size_t)a] > c->h_col_ptr[(size_t)b + 1] - c->h_col_ptr[(size_t)b];
-    });
-    for (int q = 0; q < n; ++q) {
-        const int j = idx[(size_t)q];
-        vn_desc[4 * q] = j;
-        vn_desc[4 * q + 1] = c->h_col_ptr[(size_t)j];
-        vn_desc[4 * q + 2] = c->h_col_ptr[(size_t)j + 1] - c->h_col_ptr[(size_t)j];
-        const int item = q >> 1, half = q & 1;
-        pos_of_var[j] = 128 * (item / 64) + 64 * half + item % 64;
-    }
+    for (size_t q = 0; q < vn.items.size(); ++q)
+        for (int half = 0; half < 2; ++half) {
+            const int j = half ? vn.items[q].second : vn.items[q].first;
+            if (j < 0) continue;
+            const int s = vn.slot[q];
+            int* vd = vn_desc + 4 * (2 * (size_t)s + half);
+            vd[0] = j;
+            vd[1] = c->h_col_ptr[(size_t)j];
+            vd[2] = dv[(size_t)j];
+            pos_of_var[j] = 128 * (s / 64) + 64 * half + s % 64;
+        }
     for (long long e = 0; e < E; ++e) edge_pos[e] = pos_of_var[c->h_edge_col[(size_t)e]];
     for (long long t = 0; t < E; ++t) col_slot[t] = edge_slot[c->h_col_edge[(size_t)t]];
+    {
+        // the kernels index LDS and the decision words with these tables: every edge its own slot inside the
+        // message array, every variable its own bit inside the decision words
+        std::vector<char> seen((size_t)slots, 0), seen_pos((size_t)2 * vn_steps * nt, 0);
+        bool ok = true;
+        for (long long e = 0; e < E && ok; ++e) {
+            const int sl = edge_slot[e];
+            ok = sl >= 0 && sl < slots && !seen[(size_t)sl];
+            if (ok) seen[(size_t)sl] = 1;
+        }
+        for (int j = 0; j < n && ok; ++j) {
+            const int q = pos_of_var[j];
+            ok = q >= 0 && q < 2 * vn_steps * nt && !seen_pos[(size_t)q];
+            if (ok) seen_pos[(size_t)q] = 1;
+        }
+        if (!ok) return fail(c, LDPC_AMD_EHIP, "internal error: the tables of the generic resident engine are inconsistent");
+    }
     {
         std::vector<int> edge_row((size_t)E);
         for (int i = 0; i < m; ++i)

@@ -46,3 +46,7 @@ ms = dec.last_decode_timing()[1]
 print("%s: m=%d n=%d E=%d, %d frames, 50 iterations%s: %s %.2f ms, %.3f Gbit/s, %.3f T edge-iterations/s, mean iterations %.1f" % (
     case, m, n, dec.E, F, " (early exit)" if early else "", dec.last_decode_kernel(), ms, F * (n - m) / ms / 1e6,
     F * dec.E * float(d_it.float().mean()) / ms / 1e9, float(d_it.float().mean())))
+# a checksum of the outputs, to compare builds of the library with each other
+import zlib
+print("   outputs crc32: words %08x iterations %08x syndrome weights %08x" % (
+    zlib.crc32(d_hard.cpu().numpy().tobytes()), zlib.crc32(d_it.cpu().numpy().tobytes()), zlib.crc32(d_sw.cpu().numpy().tobytes())))
