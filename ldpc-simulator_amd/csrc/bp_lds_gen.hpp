@@ -166,11 +166,11 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
     uint32_t mydec = 0u;
     bool converged = false;
     int iters = p.max_iters, synd = 0;
+    int4 cd_next = p.cn_desc[t];
     for (int it = 0; it < p.max_iters; ++it) {
         // check nodes: beta -> alpha in place (LogDecoder.java:82-95)
         // the descriptor of the next step is requested before this step's work: a step is a chain of dependent
         // reads (descriptor, then slots) and few waves share a SIMD here
-        int4 cd_next = p.cn_desc[t];
         for (int s = 0; s < p.cn_steps; ++s) {
             const int4 cd = cd_next;
             if (s + 1 < p.cn_steps) cd_next = p.cn_desc[t + (s + 1) * nt];
@@ -186,11 +186,12 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
                 if (cd.w > 0) cn_dispatch<1, RULE, false>(cd.w, msg + cd.z, nullptr, nullptr, kGenRowStride, 1, nullptr, 0, lane);
             }
         }
+        // the first descriptors of a phase are requested before the barrier that precedes it
+        int4 va_next = p.vn_desc[2 * t], vb_next = p.vn_desc[2 * t + 1];
         __syncthreads();
         // variable nodes: alpha -> beta in place, posterior sign -> decision bit (:67-79, :98-105)
         const bool write_beta = EARLY || (it + 1 < p.max_iters);
         uint32_t newdec = 0u;
-        int4 va_next = p.vn_desc[2 * t], vb_next = p.vn_desc[2 * t + 1];
         for (int s = 0; s < p.vn_steps; ++s) {
             const int4 va = va_next, vb = vb_next;
             if (s + 1 < p.vn_steps) {
@@ -235,6 +236,7 @@ __global__ void __launch_bounds__(512, 4) bp_lds_gen_kernel(LdsGenParams p) {
             }
         }
         mydec = newdec;
+        cd_next = p.cn_desc[t];
         __syncthreads();
         if constexpr (EARLY) {
             // every wave scans all the words for itself: the same verdict everywhere without a reduction or
