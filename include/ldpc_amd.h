@@ -213,7 +213,7 @@ int ldpc_amd_decode_batch_dev(ldpc_amd_ctx* ctx, const float* d_llr, int64_t fra
  * message, LLR, decision and per-frame state arrays of the sweep kernels ("rows_cn_kernel"), which the
  * other entry points keep in a workspace they allocate, live in a static device array of
  * LDPC_AMD_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
- * Limits: the batch must fit into that array in one piece, (E + n + ceil(n/32) + 5) * 256 bytes per 64
+ * Limits: the batch must fit into that array in one piece, (E + n + ceil(n/32) + 35) * 256 bytes per 64
  * frames -- 1,984 frames of a (3,6) n = 4096 code, 192 of an NR-BG1-sized Z = 384 code, 128 of an
  * n = 64800 (3,6) code (ldpc_amd_get_option(LDPC_AMD_OPT_NOALLOC_MAX_FRAMES) gives the number for the
  * context's code); a larger batch fails with LDPC_AMD_ELIMIT and nothing is launched.  The engine options

@@ -24,6 +24,13 @@
 
 namespace ldpc {
 
+// The waves of a launch add their rows' share of a frame's syndrome weight into that frame's accumulator.  With one
+// accumulator per frame every wave of a tile sends its atomic to the same two cache lines, and a small batch (one
+// tile, thousands of waves) waits for them in a row: there the accumulators are kept in kSyndParts parts in different
+// lines (RowsParams::synd_parts = kSyndParts; 1 for the large batches, whose tiles spread the traffic by themselves
+// and whose variable-node waves would only pay for reading the parts).
+constexpr int kSyndParts = 16;
+
 struct RowsParams {
     BpParams b;          // graph, workspace arrays, strides, tiles, frame_base, frames_total, max_iters
     int rows_per_chunk;  // checks per wave in a CN / syndrome launch
@@ -32,7 +39,9 @@ struct RowsParams {
     int early;           // per-frame early termination
     int fused;           // early termination without launches of its own (see above)
     int32_t* st_done;    // [tiles*T] 0 = still iterating (early mode)
-    int32_t* st_acc;     // [2][slots] syndrome weight accumulators, by parity of the iteration they belong to
+    int32_t* st_acc;     // [2][synd_parts][slots] syndrome weight accumulators, by parity of the iteration they belong to;
+                         // a wave adds to part (its chunk mod synd_parts), the readers sum the parts
+    int synd_parts;      // 1 or kSyndParts (a power of two)
     int slots;           // tiles * T
     int32_t* st_iters;   // [tiles*T]
     int32_t* st_synd;    // [tiles*T]
@@ -49,47 +58,74 @@ __device__ __forceinline__ bool rows_lane_active(const RowsParams& p, int tile, 
 }
 
 // number of unsatisfied checks among rows i0 .. i1-1 of the packed decisions (sumSyndro, LogDecoder.java:108-116),
-// for the check-node launch that carries the syndrome of the previous iteration: a small batch waits on every
-// round trip, so eight loads go out at a time
+// for the check-node launch that carries the syndrome of the previous iteration.  A small batch waits on every
+// round trip, so the decision words of four rows of at most eight members each are requested together (32 loads in
+// flight); a longer row goes eight loads at a time.  Row pointers and members are the same in every lane: scalar.
+template <int FPL>
+__device__ __forceinline__ void rows_syndrome_row(const BpParams& b, const uint32_t* bits, int e0, int e1, int (&w)[FPL]) {
+    uint32_t par[FPL];
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) par[f] = 0u;
+    for (int e = e0; e < e1; e += 8) {
+        int j[8];
+        uint32_t v[8][FPL];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) j[u] = (e + u < e1) ? idx(b.edge_col, e + u) : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j[u] >= 0) ldw<FPL>(bits + (long long)(j[u] >> 5) * b.bits_row, v[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j[u] >= 0) {
+#pragma unroll
+                for (int f = 0; f < FPL; ++f) par[f] ^= v[u][f] >> (j[u] & 31);
+            }
+    }
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) w[f] += (int)(par[f] & 1u);
+}
 template <int FPL>
 __device__ __forceinline__ void rows_syndrome(const BpParams& b, const uint32_t* bits, int i0, int i1, int (&w)[FPL]) {
 #pragma unroll
     for (int f = 0; f < FPL; ++f) w[f] = 0;
-    for (int i = i0; i < i1; ++i) {
-        const int e0 = idx(b.row_ptr, i), e1 = idx(b.row_ptr, i + 1);
-        uint32_t par[FPL];
+    constexpr int R = 4, D = 8;
+    for (int i = i0; i < i1; i += R) {
+        int rp[R + 1];
 #pragma unroll
-        for (int f = 0; f < FPL; ++f) par[f] = 0u;
-        int e = e0;
-        for (; e + 8 <= e1; e += 8) {  // eight loads in flight: the row is a chain of cache hits otherwise
-            int j[8];
-            uint32_t v[8][FPL];
+        for (int g = 0; g <= R; ++g) rp[g] = idx(b.row_ptr, min(i + g, i1));
+        bool short_rows = true;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) j[u] = idx(b.edge_col, e + u);
+        for (int g = 0; g < R; ++g) short_rows = short_rows && rp[g + 1] - rp[g] <= D;
+        if (short_rows) {
+            int j[R][D];
+            uint32_t v[R][D][FPL];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) ldw<FPL>(bits + (long long)(j[u] >> 5) * b.bits_row, v[u]);
+            for (int g = 0; g < R; ++g)
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < D; ++u) j[g][u] = (rp[g] + u < rp[g + 1]) ? idx(b.edge_col, rp[g] + u) : -1;
 #pragma unroll
-                for (int f = 0; f < FPL; ++f) par[f] ^= v[u][f] >> (j[u] & 31);
+            for (int g = 0; g < R; ++g)
+#pragma unroll
+                for (int u = 0; u < D; ++u)
+                    if (j[g][u] >= 0) ldw<FPL>(bits + (long long)(j[g][u] >> 5) * b.bits_row, v[g][u]);
+#pragma unroll
+            for (int g = 0; g < R; ++g) {
+                uint32_t par[FPL];
+#pragma unroll
+                for (int f = 0; f < FPL; ++f) par[f] = 0u;
+#pragma unroll
+                for (int u = 0; u < D; ++u)
+                    if (j[g][u] >= 0) {
+#pragma unroll
+                        for (int f = 0; f < FPL; ++f) par[f] ^= v[g][u][f] >> (j[g][u] & 31);
+                    }
+#pragma unroll
+                for (int f = 0; f < FPL; ++f) w[f] += (int)(par[f] & 1u);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < R; ++g) rows_syndrome_row<FPL>(b, bits, rp[g], rp[g + 1], w);
         }
-        if (e < e1) {  // the rest of the row, again all at once
-            int j[8];
-            uint32_t v[8][FPL];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) j[u] = (e + u < e1) ? idx(b.edge_col, e + u) : -1;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (j[u] >= 0) ldw<FPL>(bits + (long long)(j[u] >> 5) * b.bits_row, v[u]);
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (j[u] >= 0) {
-#pragma unroll
-                    for (int f = 0; f < FPL; ++f) par[f] ^= v[u][f] >> (j[u] & 31);
-                }
-        }
-#pragma unroll
-        for (int f = 0; f < FPL; ++f) w[f] += (int)(par[f] & 1u);
     }
 }
 
@@ -118,7 +154,9 @@ __global__ void __launch_bounds__(256, 4) rows_cn_kernel(RowsParams p) {
         if constexpr (FUSED) {  // weight of the previous iteration's syndrome over this wave's rows
             int w[1];
             rows_syndrome<1>(p.b, p.b.ws_bits + (long long)tile * p.b.bits_tile, i0, i1, w);
-            if (w[0]) atomicAdd(&p.st_acc[(long long)((p.iter - 1) & 1) * p.slots + (long long)tile * kWave + lane], w[0]);
+            if (w[0])
+                atomicAdd(&p.st_acc[(long long)(((p.iter - 1) & 1) * p.synd_parts + (chunk & (p.synd_parts - 1))) * p.slots +
+                                    (long long)tile * kWave + lane], w[0]);
         }
         if constexpr (DC > 0) {
             constexpr int G = rows_group<FPL, DC>();
@@ -158,7 +196,13 @@ __global__ void __launch_bounds__(256, 4) rows_vn_kernel(RowsParams p, int write
         {
             // the check-node launch of this iteration has left the weight of the previous iteration's syndrome
             const long long slot = (long long)tile * kWave + lane;
-            const int w = p.st_acc[(long long)((p.iter - 1) & 1) * p.slots + slot];
+            int w = 0;
+            if (p.synd_parts == 1) {
+                w = p.st_acc[(long long)((p.iter - 1) & 1) * p.slots + slot];
+            } else {  // all parts requested together
+#pragma unroll
+                for (int k = 0; k < kSyndParts; ++k) w += p.st_acc[(long long)(((p.iter - 1) & 1) * kSyndParts + k) * p.slots + slot];
+            }
             if (chunk == 0) {  // one wave per tile keeps the books
                 if (active) {
                     p.st_synd[slot] = w;
@@ -167,7 +211,8 @@ __global__ void __launch_bounds__(256, 4) rows_vn_kernel(RowsParams p, int write
                         p.st_iters[slot] = p.iter;
                     }
                 }
-                p.st_acc[(long long)(p.iter & 1) * p.slots + slot] = 0;  // last read one launch pair ago
+                for (int k = 0; k < p.synd_parts; ++k)
+                    p.st_acc[(long long)((p.iter & 1) * p.synd_parts + k) * p.slots + slot] = 0;  // last read one launch pair ago
             }
             active = active && w != 0;
         }
@@ -236,7 +281,8 @@ __global__ void __launch_bounds__(256, 4) rows_synd_kernel(RowsParams p) {
 #pragma unroll
         for (int f = 0; f < FPL; ++f) w[f] += (int)(par[f] & 1u);
     }
-    int32_t* acc = p.st_acc + (long long)(p.iter & 1) * p.slots + (long long)tile * (kWave * FPL) + lane * FPL;
+    int32_t* acc = p.st_acc + (long long)((p.iter & 1) * p.synd_parts + (chunk & (p.synd_parts - 1))) * p.slots +
+                   (long long)tile * (kWave * FPL) + lane * FPL;
 #pragma unroll
     for (int f = 0; f < FPL; ++f)
         if (w[f]) atomicAdd(&acc[f], w[f]);
@@ -247,8 +293,11 @@ __global__ void __launch_bounds__(256) rows_finish_kernel(RowsParams p, int slot
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= slots) return;
     if (p.early && p.st_done[s]) return;
-    const int w = p.st_acc[(long long)(p.iter & 1) * p.slots + s];
-    p.st_acc[(long long)(p.iter & 1) * p.slots + s] = 0;
+    int w = 0;
+    for (int k = 0; k < p.synd_parts; ++k) {
+        w += p.st_acc[(long long)((p.iter & 1) * p.synd_parts + k) * p.slots + s];
+        p.st_acc[(long long)((p.iter & 1) * p.synd_parts + k) * p.slots + s] = 0;
+    }
     p.st_synd[s] = w;
     if (p.early && w == 0) {
         p.st_done[s] = 1;
