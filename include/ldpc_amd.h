@@ -148,8 +148,9 @@ int ldpc_amd_set_workspace_limit(ldpc_amd_ctx* ctx, uint64_t bytes);
                                                of the next iteration (1), in launches of its own (0), -1 = the library's choice (inside, at every batch size) */
 #define LDPC_AMD_OPT_TUNE_ROWS_LEAVES 112    /* sweeps at fixed iterations: 1 (default) = iterations 1 .. L-2 leave variables of
                                                 degree 1 alone (same results, less traffic); 0 = every sweep touches them */
-#define LDPC_AMD_OPT_TUNE_SIM_CHUNK_MB 113   /* ldpc_amd_simulate: MiB of received and decoded words per chunk of a leg (default 2048;
-                                                a leg holds two such sets when its chunks overlap) */
+#define LDPC_AMD_OPT_TUNE_SIM_CHUNK_MB 113   /* ldpc_amd_simulate: MiB of received and decoded words per chunk of a leg; 0 (default) =
+                                                a sixteenth of the free device memory, between 256 and 8192.  A leg holds two
+                                                such sets when its chunks overlap, and three chunks of codewords */
 #define LDPC_AMD_OPT_TUNE_NODES_FLAT_BARRIER 114 /* node-parallel kernel: 1 = every grid barrier is the one-level one (each workgroup
                                                 releases and arrives at one counter); 0 (default) = workgroups meet per XCD first.
                                                 Same results; the A/B also checks the two-level barrier's visibility assumptions */

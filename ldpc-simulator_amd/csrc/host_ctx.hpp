@@ -35,7 +35,7 @@ struct Options {
     int sim_overlap = 1;
     int sim_fused = 1;
     int rows_leaves = 1;
-    int sim_chunk_mb = 2048;
+    int sim_chunk_mb = 0;
     int verbose = 0;
     int lds_wpe = 0, lds_fpw = 0, generic_lds_kb = 0, nodes_blocks = 0, fpl = 0, layout = 0, rows_waves = 0, wps = 0,
         nopipe = 0, rows_fused = -1, generic_threads = 0, lds_vpt = 0;
@@ -80,6 +80,10 @@ struct ldpc_amd_ctx {
     hipStream_t io_stream[2] = {nullptr, nullptr};
     hipEvent_t io_decoded[2] = {nullptr, nullptr};
     hipEvent_t sim_enter = nullptr;  // ldpc_amd_simulate_dev: the caller's stream at the time of the call
+    hipEvent_t sim_generated[2] = {nullptr, nullptr}, sim_decoded[2] = {nullptr, nullptr};  // simulate: a buffer set is full / free again
+    hipEvent_t sim_begin = nullptr;                                      // simulate: the decode stream at the start of a leg
+    hipStream_t sim_cw_stream = nullptr;                                 // simulate: random codewords, two chunks ahead
+    hipEvent_t sim_cw_done[3] = {nullptr, nullptr, nullptr}, sim_cw_free[3] = {nullptr, nullptr, nullptr};
     unsigned long long* d_counters = nullptr;
     size_t counters_len = 0;
     // generator matrix for random codewords, by columns: n columns of ceil(k / 64) words, row i at bit i & 63

@@ -166,6 +166,16 @@ int ldpc_amd_destroy(ldpc_amd_ctx* c) {
             if (c->io_decoded[i]) (void)hipEventDestroy(c->io_decoded[i]);
         }
         if (c->sim_enter) (void)hipEventDestroy(c->sim_enter);
+        for (int i = 0; i < 2; ++i) {
+            if (c->sim_generated[i]) (void)hipEventDestroy(c->sim_generated[i]);
+            if (c->sim_decoded[i]) (void)hipEventDestroy(c->sim_decoded[i]);
+        }
+        for (int i = 0; i < 3; ++i) {
+            if (c->sim_cw_done[i]) (void)hipEventDestroy(c->sim_cw_done[i]);
+            if (c->sim_cw_free[i]) (void)hipEventDestroy(c->sim_cw_free[i]);
+        }
+        if (c->sim_cw_stream) (void)hipStreamDestroy(c->sim_cw_stream);
+        if (c->sim_begin) (void)hipEventDestroy(c->sim_begin);
         if (c->small_host) (void)hipHostFree(c->small_host);
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -235,7 +245,7 @@ int ldpc_amd_set_option(ldpc_amd_ctx* c, int32_t key, int64_t value) {
         case LDPC_AMD_OPT_TUNE_NOPIPE: if (!range(0, 1)) break; o.nopipe = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_ROWS_FUSED: if (!range(-1, 1)) break; o.rows_fused = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_ROWS_LEAVES: if (!range(0, 1)) break; o.rows_leaves = v; return LDPC_AMD_OK;
-        case LDPC_AMD_OPT_TUNE_SIM_CHUNK_MB: if (!range(16, 65536)) break; o.sim_chunk_mb = v; return LDPC_AMD_OK;
+        case LDPC_AMD_OPT_TUNE_SIM_CHUNK_MB: if (value != 0 && !range(16, 65536)) break; o.sim_chunk_mb = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_LDS_VPT: if (!(value == 0 || value == 8 || value == 12 || value == 16)) break; o.lds_vpt = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TUNE_GENERIC_THREADS: if (!(value == 0 || (value >= 64 && value <= 512 && value % 64 == 0))) break; o.generic_threads = v; return LDPC_AMD_OK;
         case LDPC_AMD_OPT_TEST_NODES_OVERSIZE: if (!range(0, 1)) break; o.test_nodes_oversize = v; return LDPC_AMD_OK;
@@ -535,28 +545,56 @@ static int simulate_leg(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t
         if (int rc = bsc_magnitudes(c, param, mode, &l0, &l1)) return rc;
     }
     const size_t in_elem = awgn ? sizeof(float) : 1;
-    long long chunk = (long long)(((unsigned long long)c->opt.sim_chunk_mb << 20) / (n * (in_elem + 1) + 8));
+    unsigned long long chunk_mb = (unsigned long long)c->opt.sim_chunk_mb;
+    if (!chunk_mb) {
+        // larger chunks leave fewer half-empty last rounds of workgroups (one leg of the (3,6) n = 4096 code at 4 dB:
+        // 2048 -> 8192 MiB + 3 to 8 %); what the staging buffers already hold counts as free
+        size_t fr = 0, tot = 0;
+        LDPC_HIP(c, hipMemGetInfo(&fr, &tot));
+        size_t held = c->stage_cw_bytes;
+        for (int i = 0; i < 8; ++i) held += c->stage_bytes[i];
+        chunk_mb = std::min<unsigned long long>(8192, std::max<unsigned long long>(256, ((fr + held) >> 20) / 16));
+    }
+    long long chunk = (long long)((chunk_mb << 20) / (n * (in_elem + 1) + 8));
     chunk = std::max<long long>(256, std::min<long long>(chunk, 1ll << 20));
     chunk = std::min<long long>(chunk, std::max<long long>(frames, 1));
-    // Chunks alternate between two sets of buffers on two streams: the channel generation of chunk i + 1
-    // and the error accounting of chunk i - 1 (HBM-bound, no LDS) run in the wave slots the resident
-    // decode kernel of chunk i (VALU-bound, all of the LDS) leaves free.  Engines that keep their
-    // messages in the context's one workspace must not overlap: they stay on one stream and one set.
+    // The decodes follow each other on one stream; the channel of chunk i + 1 is generated on a second stream and the
+    // random codewords of chunk i + 2 on a third while chunk i is decoded: the channel kernel (HBM-bound, no LDS) runs in
+    // the wave slots the resident decode kernel (VALU-bound, all of the LDS) leaves free, the codeword kernel needs LDS and
+    // gets its blocks in as decode workgroups leave, and no two decodes ever share the GPU.  (Two streams that each
+    // generated and decoded their own chunks ran in step: both generating, then both decoding.)  LLRs and results have
+    // two sets of buffers, codewords three; a set is written once the decode that last read it is over, and read once
+    // it is full.  Engines whose sweeps are HBM-bound themselves gain nothing from the overlap: one stream, one set.
     for (int i = 0; i < 2; ++i) {
         if (!c->io_stream[i]) LDPC_HIP(c, hipStreamCreateWithFlags(&c->io_stream[i], hipStreamNonBlocking));
         if (!c->io_decoded[i]) LDPC_HIP(c, hipEventCreateWithFlags(&c->io_decoded[i], hipEventDisableTiming));
+        if (!c->sim_generated[i]) LDPC_HIP(c, hipEventCreateWithFlags(&c->sim_generated[i], hipEventDisableTiming));
+        if (!c->sim_decoded[i]) LDPC_HIP(c, hipEventCreateWithFlags(&c->sim_decoded[i], hipEventDisableTiming));
     }
+    if (!c->sim_cw_stream) LDPC_HIP(c, hipStreamCreateWithFlags(&c->sim_cw_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 3; ++i) {
+        if (!c->sim_cw_done[i]) LDPC_HIP(c, hipEventCreateWithFlags(&c->sim_cw_done[i], hipEventDisableTiming));
+        if (!c->sim_cw_free[i]) LDPC_HIP(c, hipEventCreateWithFlags(&c->sim_cw_free[i], hipEventDisableTiming));
+    }
+    hipStream_t sd = c->io_stream[0];  // decodes
     if (ordered) {
         if (!c->sim_enter) LDPC_HIP(c, hipEventCreateWithFlags(&c->sim_enter, hipEventDisableTiming));
         LDPC_HIP(c, hipEventRecord(c->sim_enter, user));
         for (int i = 0; i < 2; ++i) LDPC_HIP(c, hipStreamWaitEvent(c->io_stream[i], c->sim_enter, 0));
+        LDPC_HIP(c, hipStreamWaitEvent(c->sim_cw_stream, c->sim_enter, 0));
     }
+    // the generators of this leg write the buffers the decodes of the leg before it may still be reading
+    if (!c->sim_begin) LDPC_HIP(c, hipEventCreateWithFlags(&c->sim_begin, hipEventDisableTiming));
+    LDPC_HIP(c, hipEventRecord(c->sim_begin, sd));
+    LDPC_HIP(c, hipStreamWaitEvent(c->io_stream[1], c->sim_begin, 0));
+    LDPC_HIP(c, hipStreamWaitEvent(c->sim_cw_stream, c->sim_begin, 0));
     bool overlap = false;
     long long index = 0;
     for (long long f0 = 0; f0 < frames; f0 += chunk, ++index) {
         const long long nf = std::min<long long>(chunk, frames - f0);
-        const int set = overlap ? (int)(index & 1) : 0;
-        hipStream_t s = c->io_stream[set];
+        const int set = overlap ? (int)(index & 1) : 0, cw_set = overlap ? (int)(index % 3) : 0;
+        hipStream_t sg = overlap ? c->io_stream[1] : sd;     // channel
+        hipStream_t sc = overlap ? c->sim_cw_stream : sd;    // codewords
         void** st = c->stage + 4 * set;
         if (int rc = ensure_stage(c, 4 * set + 0, (size_t)nf * n * in_elem)) return rc;
         if (int rc = ensure_stage(c, 4 * set + 1, (size_t)nf * n)) return rc;
@@ -565,49 +603,71 @@ static int simulate_leg(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t
         int rc;
         const uint8_t* cw = nullptr;  // transmitted words of this chunk; null = the all-zero word
         if (c->d_gen) {
-            if (c->stage_cw_bytes < (size_t)2 * chunk * n) {
+            if (c->stage_cw_bytes < (size_t)3 * chunk * n) {
                 LDPC_HIP(c, hipStreamSynchronize(c->io_stream[0]));
                 LDPC_HIP(c, hipStreamSynchronize(c->io_stream[1]));
+                LDPC_HIP(c, hipStreamSynchronize(c->sim_cw_stream));
                 if (c->stage_cw) LDPC_HIP(c, hipFree(c->stage_cw));
                 c->stage_cw = nullptr;
                 c->stage_cw_bytes = 0;
-                LDPC_HIP(c, hipMalloc(&c->stage_cw, (size_t)2 * chunk * n));
-                c->stage_cw_bytes = (size_t)2 * chunk * n;
+                LDPC_HIP(c, hipMalloc(&c->stage_cw, (size_t)3 * chunk * n));
+                c->stage_cw_bytes = (size_t)3 * chunk * n;
             }
-            uint8_t* mine = (uint8_t*)c->stage_cw + (size_t)set * chunk * n;
-            rc = gen_codewords(c, seed, first_frame + f0, nf, mine, s);
+            uint8_t* mine = (uint8_t*)c->stage_cw + (size_t)cw_set * chunk * n;
+            // the words of chunk index - 3 were last read by its decode
+            if (overlap && index >= 3) LDPC_HIP(c, hipStreamWaitEvent(sc, c->sim_cw_free[cw_set], 0));
+            rc = gen_codewords(c, seed, first_frame + f0, nf, mine, sc);
             if (rc) return rc;
             cw = mine;
+            if (overlap) {
+                LDPC_HIP(c, hipEventRecord(c->sim_cw_done[cw_set], sc));
+                LDPC_HIP(c, hipStreamWaitEvent(sg, c->sim_cw_done[cw_set], 0));
+            }
         }
+        // the set's LLRs and results are free once the decode (and accounting) of chunk index - 2 is over
+        if (overlap && index >= 2) LDPC_HIP(c, hipStreamWaitEvent(sg, c->sim_decoded[set], 0));
         SrcArgs src{};
         if (awgn) {
-            rc = gen_awgn(c, param, seed, first_frame + f0, nf, cw, (float*)st[0], s);
+            rc = gen_awgn(c, param, seed, first_frame + f0, nf, cw, (float*)st[0], sg);
             src = SrcArgs{Src::Float, (const float*)st[0], nullptr, 0.0, 0.0};
         } else {
-            rc = gen_bsc(c, channel, param, seed, first_frame + f0, nf, cw, (uint8_t*)st[0], s);
+            rc = gen_bsc(c, channel, param, seed, first_frame + f0, nf, cw, (uint8_t*)st[0], sg);
             src = SrcArgs{Src::Bsc, nullptr, (const uint8_t*)st[0], l0, l1};
         }
         if (rc) return rc;
+        if (overlap) {
+            LDPC_HIP(c, hipEventRecord(c->sim_generated[set], sg));
+            LDPC_HIP(c, hipStreamWaitEvent(sd, c->sim_generated[set], 0));
+        }
         // the frame-resident kernels of the (6,3) and (8,2) codes count the errors themselves; for every other
         // engine the accounting is a pass of its own over the decoder's outputs
         CountArgs count{cw, d_cnt, true, false};
-        rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)st[1], (int32_t*)st[2], (int32_t*)st[3], s, false, &count);
+        rc = decode_dev(c, src, nf, max_iters, early_term, (uint8_t*)st[1], (int32_t*)st[2], (int32_t*)st[3], sd, false, &count);
         if (rc) return rc;
         if (!strcmp(c->last_kernel, "bp_nodes_kernel")) {
             // a chunk of a few frames went through the cooperative kernel: its barriers are bounded waits, and a
             // wait that gave up must not be counted as a decode
-            LDPC_HIP(c, hipStreamSynchronize(s));
+            LDPC_HIP(c, hipStreamSynchronize(sd));
             if (int brc = check_nodes_barrier(c)) return brc;
         }
         if (!count.done)
             rc = count_launch(c, nf, (const uint8_t*)st[1], cw, awgn ? nullptr : (const uint8_t*)st[0],
                               awgn ? (const float*)st[0] : nullptr, (const int32_t*)st[2], (const int32_t*)st[3], max_iters,
-                              d_cnt, s);
+                              d_cnt, sd);
         if (rc) return rc;
         if (index == 0) {
             const char* k = c->last_kernel;
             overlap = k && (!strcmp(k, "bp_lds_kernel") || !strcmp(k, "bp_lds_gen_kernel")) && c->opt.sim_overlap != 0;
         }
+        if (overlap) {
+            LDPC_HIP(c, hipEventRecord(c->sim_decoded[index & 1], sd));
+            LDPC_HIP(c, hipEventRecord(c->sim_cw_free[index % 3], sd));
+        }
+    }
+    if (ordered) {
+        if (!c->sim_cw_done[0]) return fail(c, LDPC_AMD_EHIP, "simulate: no event");
+        LDPC_HIP(c, hipEventRecord(c->sim_cw_done[0], c->sim_cw_stream));
+        LDPC_HIP(c, hipStreamWaitEvent(user, c->sim_cw_done[0], 0));
     }
     if (ordered)
         for (int i = 0; i < 2; ++i) {
@@ -638,6 +698,7 @@ int ldpc_amd_simulate(ldpc_amd_ctx* c, int32_t channel, double param, uint64_t s
         return rc;
     LDPC_HIP(c, hipStreamSynchronize(c->io_stream[0]));
     LDPC_HIP(c, hipStreamSynchronize(c->io_stream[1]));
+    LDPC_HIP(c, hipStreamSynchronize(c->sim_cw_stream));
     std::vector<unsigned long long> h(nc);
     LDPC_HIP(c, hipMemcpy(h.data(), c->d_counters, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < nc; ++i) counters[i] += h[i];
