@@ -66,3 +66,34 @@ def test_simulate_dev_rejects_what_simulate_rejects(pkg):
     torch.cuda.synchronize()
     assert not d_cnt.any()
     dec.close()
+
+
+def test_leg_counters_do_not_depend_on_the_chunking(pkg):
+    """A leg is cut into chunks that are generated ahead of their decodes on streams of their own (random codewords two
+    chunks ahead, the channel one); every counter must be the same however the leg is cut: one chunk, hundreds of small
+    ones (the buffer sets are reused many times), ragged legs at odd first frames, the library's own choice, with
+    random codewords and with the all-zero word, on the resident kernels and on the sweeps."""
+    m, n, rows, cols = pkg.codes.regular_ldpc(1536, 3, 6, 2)
+    eh, eg = pkg.encoder.systematic_pair(pkg.check_matrix_io.to_dense(m, n, rows, cols))
+    r2, c2 = np.nonzero(eh)
+    F = 200_000
+    for generator in (True, False):
+        for engine in ("auto", "stream"):
+            dec = pkg.Decoder(m, n, r2.astype(np.int32), c2.astype(np.int32))
+            if generator:
+                dec.set_generator(eg)
+            dec.set_option("engine", engine)
+            ref = None
+            for mb, cuts in ((4096, (0, F)), (16, (0, F)), (16, (0, 33_333, 100_001, F)), (64, (0, F // 2, F)), (0, (0, F))):
+                if engine == "stream" and mb == 16 and len(cuts) == 2:
+                    continue  # hundreds of sweep decodes of a thousand frames: slow, and one stream anyway
+                dec.set_option("sim_chunk_mb", mb)
+                total = None
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    c = np.asarray(dec.simulate(pkg.capi.CH_AWGN, 1.9, 11, a, b - a, 30, True)).astype(np.int64)
+                    total = c if total is None else total + c
+                if ref is None:
+                    ref = total
+                    assert 0 < ref[1] < F and ref[0] == F    # some frames fail, some do not
+                assert (total == ref).all(), (generator, engine, mb, cuts, np.nonzero(total != ref)[0].tolist())
+            dec.close()
