@@ -31,7 +31,7 @@ OPT = {
     "nodes_refusals": 200, "nodes_last_hip_error": 201, "noalloc_max_frames": 202, "nodes_barrier_timed_out": 203,
 }
 OPT_READ_ONLY = ("nodes_refusals", "nodes_last_hip_error", "noalloc_max_frames", "nodes_barrier_timed_out")
-OPT_LIBRARY_DEFAULT = {"nodes": -1, "sim_overlap": 1, "sim_fused": 1, "rows_leaves": 1, "sim_chunk_mb": 2048}   # every other option defaults to 0
+OPT_LIBRARY_DEFAULT = {"nodes": -1, "sim_overlap": 1, "sim_fused": 1, "rows_leaves": 1}   # every other option defaults to 0
 ENGINE_AUTO, ENGINE_GENERIC, ENGINE_STREAM = 0, 1, 2
 ENGINES = {"auto": ENGINE_AUTO, "generic": ENGINE_GENERIC, "stream": ENGINE_STREAM}
 

@@ -20,6 +20,9 @@ else:
     dec = L.Decoder(m, n, rows, cols)
 if os.environ.get("SIM_CHUNK_MB"):  # staging memory per set of buffers (option sim_chunk_mb)
     dec.set_option("sim_chunk_mb", int(os.environ["SIM_CHUNK_MB"]))
+for kv in os.environ.get("SIM_OPTIONS", "").split():  # e.g. SIM_OPTIONS="sim_overlap=0 sim_fused=0"
+    name, value = kv.split("=")
+    dec.set_option(name, int(value))
 dec.simulate(L.capi.CH_AWGN, ebn0, 1, 0, frames, 50, True)  # warm-up: buffers of the measured leg's size
 t0 = time.perf_counter()
 cnt = dec.simulate(L.capi.CH_AWGN, ebn0, 2, 0, frames, 50, True)
