@@ -96,4 +96,5 @@ def test_leg_counters_do_not_depend_on_the_chunking(pkg):
                     ref = total
                     assert 0 < ref[1] < F and ref[0] == F    # some frames fail, some do not
                 assert (total == ref).all(), (generator, engine, mb, cuts, np.nonzero(total != ref)[0].tolist())
+            assert not np.asarray(dec.simulate(pkg.capi.CH_AWGN, 1.9, 11, 5, 0, 30, True)).any()   # an empty leg
             dec.close()
