@@ -356,6 +356,14 @@ int run_stream(ldpc_amd_ctx* c, const DecodeCall& d, bool noalloc) {
     const int maxdeg = std::max(c->max_dc, c->max_dv);
     if (maxdeg > kLdsMaxDegree) return fail(c, LDPC_AMD_ELIMIT, "node degree above 128 is not supported");
     int fpl = (!early && maxdeg <= kRegDegFpl4 && !noalloc) ? 4 : 1;
+    // Four frames per lane move the most bytes per instruction, and make a quarter of the waves: worth it once those
+    // waves fill the chip.  Below about 4,000 waves per sweep launch one frame per lane is faster, by up to 4.7x
+    // (fixed 12 iterations, 4 -> 1: n = 64800, 64 frames 2.07 -> 0.44 ms, 256 frames 2.07 -> 1.58, 512 frames level;
+    // (3,6) n = 4096, 4,096 frames 2.10 -> 1.63, 16,384 frames 8.05 against 8.32).
+    if (fpl == 4 && c->opt.stream_kernel == 0 && !c->opt.layout) {
+        const long long coarse = std::max(1, std::min(4096, std::min(c->m / 4, n / 32)));
+        if ((frames + 255) / 256 * coarse < 4000) fpl = 1;
+    }
     if (const int v = c->opt.fpl) {
         if (!early && maxdeg <= kRegDegFpl4 && (v == 1 || v == 2 || v == 4) && !noalloc) fpl = v;
     }
@@ -439,9 +447,11 @@ int run_stream(ldpc_amd_ctx* c, const DecodeCall& d, bool noalloc) {
         // (NR-BG1-sized code, 64 frames: 119 -> 43 us per iteration, 512 frames: 306 -> 234; from 2048 frames
         // on the coarse cut is as good or better).  Eight variables share a byte of the packed decisions,
         // which such a wave stores as a byte; cuts between 17 and 31 variables measured far slower than
-        // either neighbour and are not used.  The kernels specialised for a regular code issue the loads of
-        // several rows together and lose by a finer cut.
-        const bool specialised = (c->reg_dc == 6 && c->reg_dv == 3) || (c->reg_dc == 8 && c->reg_dv == 2);
+        // either neighbour and are not used.  The kernels specialised for a regular code, which issue the loads
+        // of several rows together, had lost by a finer cut while every wave of a launch queued its syndrome atomic on
+        // one frame's accumulator; with the accumulators in parts (RowsParams::synd_parts) they gain like the others
+        // ((3,6) n = 4096 through the sweeps, early termination: 64 frames 0.78 -> 0.38 ms, 1024 frames 1.10 -> 0.92;
+        // n = 64800: 64 frames 1.14 -> 0.98; never slower up to 65,536 frames).
         long long want = 32768;
         if (c->opt.rows_waves) want = std::max(256, c->opt.rows_waves);  // measurements: waves per launch
         if (c->opt.rows_waves && (long long)chunks * tiles_per_round > want)
@@ -453,7 +463,7 @@ int run_stream(ldpc_amd_ctx* c, const DecodeCall& d, bool noalloc) {
         // addresses on the scalar unit it had cost the large batches of irregular codes 4.5 %.
         fuse_syndrome = early && fpl == 1;
         if (c->opt.rows_fused >= 0) fuse_syndrome = early && fpl == 1 && c->opt.rows_fused != 0;
-        if (fpl == 1 && !specialised && (long long)chunks * tiles_per_round < want) {
+        if (fpl == 1 && (long long)chunks * tiles_per_round < want) {
             const long long finest = std::max(1, std::min(c->m / 2, n / 8));
             const long long finer = std::min<long long>((want + tiles_per_round - 1) / tiles_per_round, finest);
             if (finer >= (n + 15) / 16) chunks = (int)std::max<long long>(chunks, finer);
