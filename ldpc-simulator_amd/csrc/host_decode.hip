@@ -267,11 +267,11 @@ int try_nodes(ldpc_amd_ctx* c, const DecodeCall& d, bool* taken) {
     bool use = can;
     // Per iteration this engine costs two grid barriers and the latency of two dependent phases (about
     // 14 us together) plus about 45 ns per 1000 edges of the batch (gathers of single words); the sweeps
-    // cost two launches of short waves: about 80 us with the kernels specialised for a regular code, and
+    // cost two launches of short waves: about 60 us with the kernels specialised for a regular code, and
     // 70 us plus a round trip per variable of the largest degree otherwise (measured on an NR-BG1-sized
-    // code and on a (3,6) code of n = 64800: break-even near 20 and near 9 frames).
+    // code and on a (3,6) code of n = 64800: break-even near 20 and near 5 frames).
     const bool specialised_rows = (c->reg_dc == 6 && c->reg_dv == 3) || (c->reg_dc == 8 && c->reg_dv == 2);
-    const double sweeps_us = specialised_rows ? 80.0 : 70.0 + 0.9 * c->max_dv;
+    const double sweeps_us = specialised_rows ? 60.0 : 70.0 + 0.9 * c->max_dv;
     use = use && 14.0 + 4.5e-5 * (double)frames * (double)c->E < sweeps_us;
     if (c->opt.nodes >= 0) use = can && c->opt.nodes != 0;  // 0: never, 1: whenever the batch and the degrees allow
     if (use && c->nodes_blocks == 0) {
